@@ -1,0 +1,167 @@
+"""Pins the CPU oracle (oracle/) to the reference: every golden vector under tests/golden/ was
+produced by the reference's own code (tests/golden/make_golden.py).  CPU only."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import boxes as OB
+from oracle import detect as OD
+from oracle import metrics as OM
+from oracle import multibox as OMB
+from oracle import priors as OP
+from oracle.network import OracleSSD3D
+from oracle.train_step import make_optimizer
+from tests.golden import cases, detinit
+from tests.util import golden, oracle_model
+
+
+@pytest.mark.parametrize("tag,size", [("64", (64, 64, 64)), ("128", (128, 128, 128)),
+                                      ("192", (192, 192, 192)), ("48x64x64", (48, 64, 64))])
+def test_priors_bit_exact(tag, size):
+    g = golden("priors")
+    dims, chans = OP.feature_map_dims(size)
+    assert np.array_equal(np.array([dims[i] for i in range(8)]), g[f"fmap_dims_{tag}"])
+    assert np.array_equal(np.array(chans), g[f"fmap_chans_{tag}"])
+    scales = OP.default_scales((3, 5, 7), size)
+    assert np.array_equal(np.array([scales[k] for k in (3, 5, 7)]), g[f"scales_{tag}"])
+    p = OP.make_priors({f: dims[f] for f in (3, 5, 7)}, scales).numpy()
+    assert p.shape[0] == int(g[f"n_{tag}"])
+    assert hashlib.sha256(p.tobytes()).digest() == bytes(g[f"sha256_{tag}"])
+    assert np.array_equal(p[::97], g[f"stride97_{tag}"])
+
+
+def test_state_dict_inventory():
+    g = golden("priors")
+    m = OracleSSD3D(emulate_reference_init=False)
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["sd_keys"])
+    assert [v.numel() for v in sd.values()] == list(g["sd_numel"])
+
+
+def test_seeded_construction_matches_reference():
+    """Same seed -> same default-initialised weights and the same BN side effects as the reference's
+    constructor; checked through a forward pass fixture-free: num_batches_tracked."""
+    torch.manual_seed(0)
+    m = OracleSSD3D()
+    assert int(m.base.features[0][1].num_batches_tracked) == 3
+
+
+def test_boxmath_bit_exact():
+    g = golden("boxmath")
+    a, b, gg = cases.boxmath_inputs()
+    ac = OB.xyz_to_cxcycz(a)
+    bc = OB.xyz_to_cxcycz(b)
+    bc[:, 3:] = bc[:, 3:].clamp(min=1e-3)
+    assert np.array_equal(ac.numpy(), g["xyz_to_cxcycz"])
+    assert np.array_equal(OB.cxcycz_to_xyz(ac).numpy(), g["cxcycz_to_xyz"])
+    assert np.array_equal(OB.encode(OB.xyz_to_cxcycz(b[2:26]), bc[14:38]).numpy(), g["encode"], equal_nan=True)
+    assert np.array_equal(OB.decode(gg, bc).numpy(), g["decode"])
+    assert np.array_equal(OB.intersection(a, b).numpy(), g["intersection"])
+    assert np.array_equal(OB.iou_matrix(a, b).numpy(), g["iou"], equal_nan=True)
+    assert np.array_equal(OB.iou_matrix(a, a).numpy(), g["iou_self"], equal_nan=True)
+    assert np.isnan(g["iou"]).any()  # the 0/0 case is really in the fixture
+
+
+@pytest.mark.parametrize("name", list(cases.matching_cases().keys()))
+def test_matching_and_loss(name):
+    g = golden("matching")
+    c = cases.matching_cases()[name]
+    pri = oracle_model().priors_cxcycz
+    tc, tl, _ = OMB.match_batch(c["boxes"], c["labels"], pri, c["threshold"])
+    assert np.array_equal(tc.numpy().astype(np.int8), g[f"{name}__true_classes"])
+    assert np.array_equal(tl.numpy(), g[f"{name}__true_locs"])
+    locs, scores = detinit.make_head_outputs(c["head_seed"], len(c["boxes"]), cases.P_C64)
+    locs.requires_grad_(True)
+    scores.requires_grad_(True)
+    conf, loc = OMB.multibox_loss(locs, scores, c["boxes"], c["labels"], pri, c["threshold"])
+    (conf + loc).backward()
+    assert abs(conf.item() - float(g[f"{name}__conf"])) <= 1e-6 * abs(float(g[f"{name}__conf"]))
+    assert abs(loc.item() - float(g[f"{name}__loc"])) <= 1e-6 * abs(float(g[f"{name}__loc"]))
+    np.testing.assert_allclose(locs.grad.numpy()[tc.numpy() > 0], g[f"{name}__dlocs_nz"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(scores.grad.numpy().reshape(-1)[::17], g[f"{name}__dscores_s17"], rtol=1e-5, atol=1e-9)
+
+
+def test_empty_gt_batch_raises():
+    pri = oracle_model().priors_cxcycz
+    locs, scores = detinit.make_head_outputs(1, 2, cases.P_C64)
+    with pytest.raises(Exception, match="NaN"):
+        OMB.multibox_loss(locs, scores, [torch.zeros((0, 6))] * 2, [torch.zeros((0,), dtype=torch.long)] * 2, pri, [0.1, 0.2])
+
+
+def test_bad_threshold_type_raises():
+    with pytest.raises(Exception):
+        OMB.normalize_threshold(1)
+
+
+@pytest.mark.parametrize("tag,n,cin,size,stride", [("c64", 2, 1, (64, 64, 64), 7), ("a2_2ch64", 2, 2, (64, 64, 64), 7),
+                                                    ("noncube", 2, 1, (48, 64, 64), 7), ("a128", 4, 1, (128, 128, 128), 61)])
+def test_network_forward_backward_adam(tag, n, cin, size, stride):
+    g = golden(f"network_{tag}")
+    m = oracle_model(cin, size)
+    x = detinit.make_volume_batch(5, n, cin, size)
+    boxes, labels = detinit.make_gt(8, n, size)
+    m.eval()
+    with torch.no_grad():
+        le, se = m(x)
+    assert np.array_equal(le.numpy().reshape(-1)[::stride], g["eval_locs"])
+    assert np.array_equal(se.numpy().reshape(-1)[::stride], g["eval_scores"])
+    m.train()
+    locs, scores = m(x)
+    assert np.array_equal(locs.detach().numpy().reshape(-1)[::stride], g["train_locs"])
+    assert np.array_equal(scores.detach().numpy().reshape(-1)[::stride], g["train_scores"])
+    conf, loc = OMB.multibox_loss(locs, scores, boxes, labels, m.priors_cxcycz, [0.1, 0.2])
+    (conf + loc).backward()
+    np.testing.assert_allclose(conf.item(), float(g["conf"]), rtol=1e-6)
+    np.testing.assert_allclose(loc.item(), float(g["loc"]), rtol=1e-6)
+    grads = dict((k, p.grad) for k, p in m.named_parameters() if p.grad is not None)
+    assert list(grads.keys()) == list(g["grad_names"])
+    np.testing.assert_allclose([v.double().norm().item() for v in grads.values()], g["grad_norm"], rtol=1e-5)
+    sd = m.state_dict()
+    for k in ("base.features.0.1", "base.features.1.bn1", "base.features.4.bn2", "base.features.7.bn2"):
+        assert np.array_equal(sd[k + ".running_mean"].numpy(), g[f"rm__{k}"])
+        assert np.array_equal(sd[k + ".running_var"].numpy(), g[f"rv__{k}"])
+        assert int(sd[k + ".num_batches_tracked"]) == int(g[f"nbt__{k}"]) == 1
+    if tag == "a128":
+        return  # the two-step Adam replay is covered at the small sizes
+    m2 = oracle_model(cin, size)
+    opt, sch = make_optimizer(m2, 1e-3)
+    from oracle.train_step import train_step
+    losses = []
+    for step in range(2):
+        xs = detinit.make_volume_batch(50 + step, n, cin, size)
+        bs, ls = detinit.make_gt(60 + step, n, size)
+        losses.append(train_step(m2, opt, sch, xs, bs, ls, [0.1, 0.2]))
+    np.testing.assert_allclose(np.array(losses), g["adam_losses"], rtol=1e-5)
+    np.testing.assert_allclose(sch.get_last_lr(), g["adam_lr"], rtol=1e-12)
+    assert [k for k, _ in m2.named_parameters()] == list(g["adam_param_names"])
+    np.testing.assert_allclose([p.detach().double().norm().item() for _, p in m2.named_parameters()],
+                               g["adam_param_norm"], rtol=1e-5)
+
+
+@pytest.mark.parametrize("name", list(cases.detect_cases().keys()))
+def test_detect_objects(name):
+    g = golden("detect")
+    c = cases.detect_cases()[name]
+    pri = oracle_model().priors_cxcycz
+    locs, scores = cases.detect_inputs(c)
+    b, l, s = OD.detect_objects(locs, scores, pri, c["min_score"], c["max_overlap"], c["top_k"])
+    for i in range(c["n"]):
+        assert np.array_equal(l[i].numpy(), g[f"{name}__labels_{i}"])
+        assert np.array_equal(s[i].numpy(), g[f"{name}__scores_{i}"])
+        assert np.array_equal(b[i].numpy(), g[f"{name}__boxes_{i}"])
+
+
+@pytest.mark.parametrize("name", list(cases.map_cases().keys()))
+@pytest.mark.parametrize("ov", [0.1, 0.5])
+def test_calculate_map(name, ov):
+    g = golden("map")
+    c = cases.map_cases()[name]
+    d = OM.calculate_map(c["det_boxes"], c["det_labels"], c["det_scores"], c["true_boxes"], c["true_labels"],
+                         [np.zeros(len(x), bool) for x in c["true_labels"]], min_overlap=ov)
+    tag = f"{name}__{ov}"
+    for k in ("APs", "mAP", "precision", "recall", "f1_score", "n_true_boxes"):
+        np.testing.assert_allclose(float(d[k]), float(g[f"{tag}__{k}"]), rtol=1e-6, equal_nan=True)
+    for k in ("TP", "FP", "found_boxes_volumes_per_class", "not_found_boxes_volumes_per_class"):
+        np.testing.assert_allclose(np.asarray(d[k], np.float32), g[f"{tag}__{k}"], rtol=1e-6)
