@@ -1,0 +1,140 @@
+/* mslesions3d_hip.h — C ABI of libmsl3d_hip.so: the MI355X (gfx950) kernels behind the 3D-SSD hot path.
+ *
+ * The reference (Medical-Image-Analysis-Laboratory/MSLesions3D) has no FFI: its hot path is Python calling
+ * stock torch ops.  The entry points below are what a maintainer of the reference would bind
+ * (ctypes) to replace those op sequences; each one names the reference lines it replaces.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless the comment says "host"; tensors are dense fp32, NCDHW,
+ *    W fastest; `stream` is a hipStream_t passed as void* (NULL = default stream); nothing here synchronises.
+ *  - return value: 0 on success, >0 a hipError_t from the launch, -1 bad argument, -2 unsupported shape.
+ *  - "raw" = convolution output BEFORE BatchNorm; an (in_scale, in_shift) pair is the folded BatchNorm of the
+ *    producer (scale = gamma/sqrt(var+eps), shift = beta - mean*scale); consumers apply relu(x*scale+shift)
+ *    while loading.  in_scale == NULL means "input is already an activation / a plain tensor".
+ *  - stat partials: fp64 [2][C][NP] (sum, then sum of squares) written by a conv kernel, NP from the matching
+ *    *_num_partials(); msl_bn_finalize folds them in a fixed order (bit-reproducible, no float atomics).
+ */
+#ifndef MSLESIONS3D_HIP_H
+#define MSLESIONS3D_HIP_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int msl_abi_version(void);
+
+/* ---- BatchNorm3d (train-mode batch statistics) + ReLU : mobilenet.py:29-30, :39, :41, :44-45 ------------- */
+int msl_bn_finalize(const double* partials, int num_partials, double count, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
+                    float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int C,
+                    void* stream);
+/* eval mode: scale/shift from the running statistics */
+int msl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                       float eps, float* scale, float* shift, int C, void* stream);
+/* relu(y*scale+shift) into a plain (N,C,D,H,W) tensor and/or a zero-haloed (N,C,D+2,H+2,W+2) one (either may be NULL) */
+int msl_bn_relu_materialize(const float* y, const float* scale, const float* shift, float* out_plain,
+                            float* out_pad, int N, int C, int D, int H, int W, void* stream);
+/* backward of a = relu(bn(y)):  reduce -> finalize -> apply (dy may alias g) */
+int msl_bn_relu_bwd_num_partials(int N, int S);
+int msl_bn_relu_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, double* partials, int N, int C, int S,
+                           void* stream);
+int msl_bn_bwd_finalize(const double* partials, int num_partials, double count, float* dgamma, float* dbeta,
+                        float* c1, float* c2, int C, void* stream);
+int msl_bn_relu_bwd_apply(const float* g, const float* y, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* c1, const float* c2, float* dy,
+                          int N, int C, int S, void* stream);
+
+/* ---- stem: Conv3d(Cin->32,k3,stride (sd,sh,sw),p1,no bias) : mobilenet.py:26-31 via ssd3d.py:60-61 ------- */
+int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW);
+int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D, int H,
+                      int W, int sd, int sh, int sw, void* stream);
+size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin);
+int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D,
+                             int H, int W, int sd, int sh, int sw, void* stream);
+
+/* ---- depthwise Conv3d(C,C,k3,stride s,p1,groups=C) : Block.conv1, mobilenet.py:38,44 ---------------------- */
+int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride);
+int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride); /* 0 naive, 1 stream, 2 resident */
+int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                   double* partials, int N, int C, int D, int H, int W, int stride, int force_naive, void* stream);
+int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
+                        int stride, int accumulate, void* stream);
+int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int stride);
+int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
+                          double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
+
+/* ---- pointwise Conv3d(Cin,Cout,k1) = per-image GEMM on MFMA : Block.conv2, mobilenet.py:40,45 ------------- */
+int msl_pwconv_fwd_num_partials(int N, int S);
+int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
+                   double* partials, int N, int Cin, int Cout, int S, void* stream);
+int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,
+                        void* stream);
+size_t msl_pwconv_bwd_weight_workspace_bytes(int N, int Cin, int Cout, int S);
+int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale, const float* in_shift, float* dw,
+                          float* workspace, int N, int Cin, int Cout, int S, void* stream);
+
+/* ---- detection heads: loc (C->12) + cls (C->2*ncls) k3 p1 convs, permute/view/cat fused : ssd3d.py:113-169 - */
+size_t msl_head_packed_weight_elems(int C, int ncls);
+int msl_head_pack_weights(const float* loc_w, const float* cl_w, float* Wf, float* Wb, int C, int ncls,
+                          void* stream);
+size_t msl_head_fwd_workspace_bytes(int N, int C, int D, int H, int W, int ncls);
+int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, const float* cl_b, float* locs,
+                      float* scores, float* workspace, int N, int C, int D, int H, int W, int Ptot, int prior_off,
+                      int ncls, void* stream);
+int msl_head_grad_pack(const float* dlocs, const float* dscores, float* dO_pad, int N, int D, int H, int W,
+                       int Ptot, int prior_off, int ncls, void* stream);
+int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int N, int C, int D, int H, int W,
+                           int ncls, void* stream);
+size_t msl_head_bwd_weight_workspace_bytes(int N, int C, int D, int H, int W, int ncls);
+int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dloc_w, float* dcl_w, float* dloc_b,
+                             float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls,
+                             void* stream);
+
+/* ---- priors, box math, matching, MultiBox loss : ssd3d.py:286-342, utils.py:42-149, ssd3d.py:741-941 ------- */
+int msl_make_priors(float* out, int row_off, int D0, int D1, int D2, double scale, int boxes_per_location,
+                    void* stream);
+/* op 0 cxcycz_to_xyz (utils.py:42) 1 xyz_to_cxcycz (:92) 2 cxcycz_to_gcxgcygcz (:71) 3 gcxgcygcz_to_cxcycz (:54) */
+int msl_box_transform(const float* boxes, const float* priors, float* out, int n, int op, void* stream);
+/* find_jaccard_overlap3d (utils.py:125) / find_intersection3d (utils.py:105) */
+int msl_iou_matrix(const float* set1, const float* set2, float* out, int n1, int n2, int intersection_only,
+                   void* stream);
+/* MultiBoxLoss.forward matching part (ssd3d.py:786-887) for the whole batch.  gt_* are the per-image lists
+ * concatenated; obj_off (N+1) int32 prefix offsets.  scratch: overlap (N,P) f32, obj (N,P) i32,
+ * prior_for_obj (T) i32.  Outputs: true_classes (N,P) i64 in {-1,0,label}, true_locs (N,P,6), matched (N,P) i64
+ * (may be NULL).  soft != 0 selects the two-threshold band of ssd3d.py:878-881. */
+int msl_multibox_match(const float* gt_boxes, const long long* gt_labels, const int* obj_off, int total_objects,
+                       const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
+                       int* obj, int* prior_for_obj, long long* true_classes, float* true_locs, long long* matched,
+                       void* stream);
+size_t msl_multibox_loss_workspace_bytes(void);
+/* loss part (ssd3d.py:890-941): loss_out[0] = conf_loss, [1] = loc_loss, [2] = number of positives */
+int msl_multibox_loss_fwd(const float* locs, const float* scores, const long long* true_classes,
+                          const float* true_locs, double* workspace, float* loss_out, int N, int P, int ncls,
+                          void* stream);
+int msl_multibox_loss_bwd(const float* locs, const float* scores, const long long* true_classes,
+                          const float* true_locs, const float* loss_out, const float* upstream, float* dlocs,
+                          float* dscores, int N, int P, int ncls, void* stream);
+
+/* ---- LSSD3D.detect_objects (ssd3d.py:344-460): softmax, decode, filter, sort, 3D NMS, top-k ---------------
+ * cap = 10*top_k (<= 4096), Wn = ceil(cap/64), K1 = ncls-1.  Caller-allocated scratch:
+ *   probs (N,K1,P) f32; boxes (N,P,6) f32; sorted_idx (N,K1,cap) i32; ncand (N*K1) i32;
+ *   mask (N,K1,cap,Wn) u64; keep_bits (N,K1,Wn) u64; nkept (N*K1) i32; tmp_scores (N,K1*cap) f32; tmp_ref same i32
+ * Outputs: out_boxes (N,top_k,6), out_scores (N,top_k), out_labels / out_prior (N,top_k) i64, out_count (N) i32. */
+int msl_detect_objects(const float* locs, const float* scores, const float* priors_c, int N, int P, int ncls,
+                       float min_score, float max_overlap, int top_k, float* probs, float* boxes, int* sorted_idx,
+                       int* ncand, unsigned long long* mask, unsigned long long* keep_bits, int* nkept,
+                       float* tmp_scores, int* tmp_ref, float* out_boxes, float* out_scores, long long* out_labels,
+                       long long* out_prior, int* out_count, void* stream);
+
+/* ---- optimiser + NaN guard : ssd3d.py:704-722, :258-261 ---------------------------------------------------- */
+/* hp (device, 8 floats): step_size(bias), step_size(other), sqrt(bias_correction2), beta1, beta2, eps,
+ * weight_decay, gradient scale.  params laid out [n_bias bias elements | the rest]. */
+int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp, int n,
+                  int n_bias, void* stream);
+int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

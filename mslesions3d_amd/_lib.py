@@ -1,0 +1,103 @@
+"""ctypes binding of libmsl3d_hip.so (C ABI declared in include/mslesions3d_hip.h).
+
+There is NO fallback: if the library is missing or a kernel launch fails, the caller gets an exception.
+torch is only used by callers for device memory and streams; no torch type crosses this boundary.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmsl3d_hip.so")
+
+_P, _I, _F, _D, _Z, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_size_t, ctypes.c_longlong
+
+# name -> (restype, argtypes); mirrors include/mslesions3d_hip.h one to one
+_SIGNATURES = {
+    "msl_abi_version": (_I, []),
+    "msl_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P]),
+    "msl_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
+    "msl_bn_relu_materialize": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msl_bn_relu_bwd_num_partials": (_I, [_I, _I]),
+    "msl_bn_relu_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_bn_bwd_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _I, _P]),
+    "msl_bn_relu_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_stem_conv_fwd_num_partials": (_I, [_I, _I, _I, _I]),
+    "msl_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_stem_conv_bwd_weight_workspace_bytes": (_Z, [_I]),
+    "msl_stem_conv_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_fwd_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
+    "msl_dwconv_fwd_variant": (_I, [_I, _I, _I, _I, _I, _I]),
+    "msl_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_weight_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
+    "msl_dwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_pwconv_fwd_num_partials": (_I, [_I, _I]),
+    "msl_pwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_pwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_pwconv_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I]),
+    "msl_pwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_head_packed_weight_elems": (_Z, [_I, _I]),
+    "msl_head_pack_weights": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "msl_head_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "msl_head_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_head_grad_pack": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_head_conv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_head_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
+    "msl_head_conv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_make_priors": (_I, [_P, _I, _I, _I, _I, _D, _I, _P]),
+    "msl_box_transform": (_I, [_P, _P, _P, _I, _I, _P]),
+    "msl_iou_matrix": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "msl_multibox_match": (_I, [_P, _P, _P, _I, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "msl_multibox_loss_workspace_bytes": (_Z, []),
+    "msl_multibox_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_multibox_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_detect_objects": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I] + [_P] * 14 + [_P]),
+    "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "msl_nan_flag": (_I, [_P, _P, _Z, _P, _I, _P]),
+}
+# msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream)
+_SIGNATURES["msl_nan_flag"] = (_I, [_P, _Z, _P, _I, _P])
+
+_lib = None
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it has not been built: there is no CPU fallback."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipKernelError(
+            f"{LIB_PATH} not found: build it with `make -C mslesions3d_amd/csrc` (or __graft_entry__.build()). "
+            "mslesions3d_amd has no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return sorted(_SIGNATURES.keys())
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def check(code, what):
+    if code != 0:
+        raise HipKernelError(f"{what} failed with code {code} "
+                             f"({'bad argument' if code == -1 else 'unsupported shape' if code == -2 else 'hipError'})")
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point and raise on a non-zero code."""
+    check(getattr(load(), name)(*args), name)

@@ -1,0 +1,248 @@
+// BatchNorm3d (train-mode batch statistics) pieces of the MobileNet-3D backbone.
+// Reference semantics: nn.BatchNorm3d + ReLU as used in lesions3d/mobilenet.py:26-31,:39-45
+// (eps 1e-5, momentum 0.1, biased variance for normalisation, unbiased for the running estimate).
+//
+// Design: the conv kernels emit per-workgroup partial (sum, sum of squares) per channel in fp64
+// (`partials[2][C][NP]`); `bn_finalize` folds them in a fixed order into the per-channel affine
+// (scale = gamma*invstd, shift = beta - mean*scale) that the NEXT kernel applies while loading
+// (relu(fma(x, scale, shift))).  The normalised activation is never written to HBM except for the
+// three feature maps the detection heads read.
+#include "common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(64) void bn_finalize_kernel(
+    const double* __restrict__ partials, int NP, double count, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
+    long long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ scale,
+    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int C) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  const double* ps = partials + (size_t)c * NP;
+  const double* pq = partials + ((size_t)C + c) * NP;
+  for (int p = lane; p < NP; p += 64) {
+    s += ps[p];
+    q += pq[p];
+  }
+  s = msl::wave_sum(s);
+  q = msl::wave_sum(q);
+  if (lane == 0) {
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const double sc = (double)gamma[c] * invstd;
+    scale[c] = (float)sc;
+    shift[c] = (float)((double)beta[c] - mean * sc);
+    save_mean[c] = (float)mean;
+    save_invstd[c] = (float)invstd;
+    if (running_mean) {
+      const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
+    }
+    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  }
+}
+
+__global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean,
+                                      const float* __restrict__ running_var, float eps,
+                                      float* __restrict__ scale, float* __restrict__ shift, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.0f / sqrtf(running_var[c] + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - running_mean[c] * sc;
+}
+
+// out = relu(y*scale+shift), written in plain NCDHW and/or in a zero-haloed layout
+// (N,C,D+2,H+2,W+2) that lets the head convolutions run without bounds checks.
+__global__ __launch_bounds__(256) void bn_relu_materialize_kernel(
+    const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    float* __restrict__ out_plain, float* __restrict__ out_pad, int C, int D, int H, int W) {
+  const int S = D * H * W;
+  const int nc = blockIdx.y;  // n*C + c
+  const int c = nc % C;
+  const float sc = scale[c], sh = shift[c];
+  const size_t base = (size_t)nc * S;
+  const int Hp = H + 2, Wp = W + 2;
+  const size_t pbase = (size_t)nc * (D + 2) * Hp * Wp;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < S; i += gridDim.x * blockDim.x) {
+    const float v = msl::act(y[base + i], sc, sh);
+    if (out_plain) out_plain[base + i] = v;
+    if (out_pad) {
+      const int w = i % W, h = (i / W) % H, d = i / (W * H);
+      out_pad[pbase + ((size_t)(d + 1) * Hp + (h + 1)) * Wp + (w + 1)] = v;
+    }
+  }
+}
+
+// ---- backward ---------------------------------------------------------------------------------
+// For a_out = relu(bn(y)), given g = dL/da_out:
+//   gm = g * [a_out > 0];  dbeta = sum gm;  dgamma = sum gm * xhat,  xhat = (y - mean) * invstd
+//   dL/dy = gamma*invstd * (gm - dbeta/n - xhat * dgamma/n)
+constexpr int BWD_CHUNK = 4096;  // elements of one (n,c) row handled by one workgroup
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(
+    const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    double* __restrict__ partials, int C, int S, int chunks) {
+  __shared__ double scratch[8];
+  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+  const size_t base = ((size_t)n * C + c) * S;
+  const int lo = chunk * BWD_CHUNK, hi = min(S, lo + BWD_CHUNK);
+  float s1 = 0.f, s2 = 0.f;
+  if ((S & 3) == 0) {
+    for (int i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
+      const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+      const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gm = fmaf(ya[k], sc, sh) > 0.f ? ga[k] : 0.f;
+        s1 += gm;
+        s2 += gm * ((ya[k] - mu) * is);
+      }
+    }
+  } else {
+    for (int i = lo + threadIdx.x; i < hi; i += 256) {
+      const float yy = y[base + i];
+      const float gm = fmaf(yy, sc, sh) > 0.f ? g[base + i] : 0.f;
+      s1 += gm;
+      s2 += gm * ((yy - mu) * is);
+    }
+  }
+  const int NP = gridDim.z * chunks;
+  const int p = n * chunks + chunk;
+  const double t1 = msl::block_sum((double)s1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    partials[(size_t)c * NP + p] = t1;
+    partials[((size_t)C + c) * NP + p] = t2;
+  }
+}
+
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __restrict__ partials, int NP,
+                                                             double count, float* __restrict__ dgamma,
+                                                             float* __restrict__ dbeta,
+                                                             float* __restrict__ c1, float* __restrict__ c2,
+                                                             int C) {
+  const int c = blockIdx.x, lane = threadIdx.x;
+  double s = 0.0, q = 0.0;
+  for (int p = lane; p < NP; p += 64) {
+    s += partials[(size_t)c * NP + p];
+    q += partials[((size_t)C + c) * NP + p];
+  }
+  s = msl::wave_sum(s);
+  q = msl::wave_sum(q);
+  if (lane == 0) {
+    dbeta[c] = (float)s;
+    dgamma[c] = (float)q;
+    c1[c] = (float)(s / count);
+    c2[c] = (float)(q / count);
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
+    const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    const float* __restrict__ c1, const float* __restrict__ c2, float* __restrict__ dy, int C, int S) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c], k1 = c1[c], k2 = c2[c];
+  const size_t base = ((size_t)n * C + c) * S;
+  if ((S & 3) == 0) {
+    for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < S; i += gridDim.x * 256 * 4) {
+      const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
+      const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+      const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float gm = fmaf(ya[k], sc, sh) > 0.f ? ga[k] : 0.f;
+        o[k] = sc * (gm - k1 - ((ya[k] - mu) * is) * k2);
+      }
+      *reinterpret_cast<float4*>(dy + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  } else {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
+      const float yy = y[base + i];
+      const float gm = fmaf(yy, sc, sh) > 0.f ? g[base + i] : 0.f;
+      dy[base + i] = sc * (gm - k1 - ((yy - mu) * is) * k2);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int msl_bn_finalize(const double* partials, int num_partials, double count, const float* gamma,
+                    const float* beta, float* running_mean, float* running_var,
+                    long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift,
+                    float* save_mean, float* save_invstd, int C, void* stream) {
+  if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
+                     count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                     shift, save_mean, save_invstd, C);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
+  if (C <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(msl::cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma,
+                     beta, running_mean, running_var, eps, scale, shift, C);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_bn_relu_materialize(const float* y, const float* scale, const float* shift, float* out_plain,
+                            float* out_pad, int N, int C, int D, int H, int W, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return MSL_ERR_ARG;
+  const int S = D * H * W;
+  dim3 grid(min(msl::cdiv(S, 256), 64), N * C);
+  hipLaunchKernelGGL(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift,
+                     out_plain, out_pad, C, D, H, W);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_bn_relu_bwd_num_partials(int N, int S) { return N * msl::cdiv(S, BWD_CHUNK); }
+
+int msl_bn_relu_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift,
+                           const float* mean, const float* invstd, double* partials, int N, int C, int S,
+                           void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
+  const int chunks = msl::cdiv(S, BWD_CHUNK);
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, g, y,
+                     scale, shift, mean, invstd, partials, C, S, chunks);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_bn_bwd_finalize(const double* partials, int num_partials, double count, float* dgamma, float* dbeta,
+                        float* c1, float* c2, int C, void* stream) {
+  if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
+                     count, dgamma, dbeta, c1, c2, C);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_bn_relu_bwd_apply(const float* g, const float* y, const float* scale, const float* shift,
+                          const float* mean, const float* invstd, const float* c1, const float* c2, float* dy,
+                          int N, int C, int S, void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
+  const int gx = min(msl::cdiv(S, 1024), 64);
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, g, y, scale,
+                     shift, mean, invstd, c1, c2, dy, C, S);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+}  // extern "C"

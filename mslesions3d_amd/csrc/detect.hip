@@ -1,0 +1,257 @@
+// Detection decoding: softmax -> box decode -> per-class score filter -> sort -> cap -> 3D greedy NMS ->
+// placeholder / global top-k.   Reference: LSSD3D.detect_objects (lesions3d/ssd3d.py:344-460).
+//
+// The reference runs a Python loop with one host sync per candidate box.  Here the whole batch is 5
+// launches and no host sync until the final counts are read:
+//   prepare  : softmax + decode for every prior (element-wise)
+//   rank     : stable descending order by counting (rank_i = #{j : s_j > s_i or (s_j == s_i and j < i)}),
+//              O(P^2) compares from LDS tiles — exact, deterministic, no sort network
+//   mask     : 64-bit suppression masks  IoU(i, j) > max_overlap  for the (<= 10*top_k) sorted candidates
+//   scan     : one wavefront walks the candidates in score order with the suppression set held as one
+//              64-bit word per lane (ssd3d.py:414-426 semantics, including "suppress all, then clear self")
+//   finalize : per image concat of classes, placeholder if empty (ssd3d.py:437-440), top-k (ssd3d.py:449-453)
+// Ties between equal scores are resolved by ascending prior index (stable order).  IoU arithmetic keeps the
+// reference's operation order with FMA contraction off, so keep-lists are bit-exact for equal inputs.
+#include "common.hpp"
+#pragma clang fp contract(off)
+
+namespace {
+
+__device__ __forceinline__ float iou6(const float* a, const float* b) {
+  float e[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float lo = fmaxf(a[i], b[i]);
+    const float hi = fminf(a[3 + i], b[3 + i]);
+    e[i] = fmaxf(hi - lo, 0.0f);
+  }
+  const float inter = e[0] * e[1] * e[2];
+  const float va = (a[3] - a[0]) * (a[4] - a[1]) * (a[5] - a[2]);
+  const float vb = (b[3] - b[0]) * (b[4] - b[1]) * (b[5] - b[2]);
+  const float uni = va + vb - inter;
+  return inter / uni;
+}
+
+// probs (N, ncls-1, P): foreground class probabilities; boxes (N, P, 6) decoded corner boxes
+__global__ __launch_bounds__(256) void detect_prepare_kernel(const float* __restrict__ locs,
+                                                             const float* __restrict__ scores,
+                                                             const float* __restrict__ priors_c,
+                                                             float* __restrict__ probs, float* __restrict__ boxes,
+                                                             int N, int P, int ncls) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N * P) return;
+  const int n = i / P, p = i % P;
+  const float* x = scores + (size_t)i * ncls;
+  float m = x[0];
+  for (int c = 1; c < ncls; ++c) m = fmaxf(m, x[c]);
+  float se = 0.f;
+  for (int c = 0; c < ncls; ++c) se += expf(x[c] - m);
+  for (int c = 1; c < ncls; ++c) probs[((size_t)n * (ncls - 1) + c - 1) * P + p] = expf(x[c] - m) / se;
+  const float* g = locs + (size_t)i * 6;
+  const float* pr = priors_c + (size_t)p * 6;
+  float cxyz[3], sz[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    cxyz[k] = g[k] * pr[3 + k] / 10.0f + pr[k];     // utils.py:67
+    sz[k] = expf(g[3 + k] / 5.0f) * pr[3 + k];      // utils.py:68
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float h = sz[k] / 2.0f;                    // utils.py:50-51
+    boxes[(size_t)i * 6 + k] = cxyz[k] - h;
+    boxes[(size_t)i * 6 + 3 + k] = cxyz[k] + h;
+  }
+}
+
+// grid (ceil(P/256), N*(ncls-1))
+__global__ __launch_bounds__(256) void detect_rank_kernel(const float* __restrict__ probs, float min_score, int P,
+                                                          int cap, int* __restrict__ sorted_idx,
+                                                          int* __restrict__ ncand) {
+  __shared__ float tile[256];
+  const int nc = blockIdx.y;
+  const float* s = probs + (size_t)nc * P;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float si = i < P ? s[i] : 0.f;
+  const bool cand = i < P && si > min_score;  // strict (ssd3d.py:388); NaN is never a candidate
+  int rank = 0;
+  for (int j0 = 0; j0 < P; j0 += 256) {
+    const int jj = j0 + threadIdx.x;
+    tile[threadIdx.x] = jj < P ? s[jj] : 0.f;
+    __syncthreads();
+    const int lim = min(256, P - j0);
+    if (cand) {
+      for (int t = 0; t < lim; ++t) {
+        const float sj = tile[t];
+        const int j = j0 + t;
+        rank += (sj > min_score) && (sj > si || (sj == si && j < i));
+      }
+    }
+    __syncthreads();
+  }
+  if (cand) {
+    if (rank < cap) sorted_idx[(size_t)nc * cap + rank] = i;
+    atomicAdd(&ncand[nc], 1);
+  }
+}
+
+// mask[nc][i][w] bit b = IoU(sorted i, sorted 64w+b) > max_overlap.   grid (ceil(cap/4), N*(ncls-1)), 4 rows/block
+__global__ __launch_bounds__(256) void detect_mask_kernel(const float* __restrict__ boxes,
+                                                          const int* __restrict__ sorted_idx,
+                                                          const int* __restrict__ ncand, float max_overlap, int P,
+                                                          int cap, int Wn, int ncls1,
+                                                          unsigned long long* __restrict__ mask) {
+  const int nc = blockIdx.y, n = nc / ncls1;
+  const int M = min(ncand[nc], cap);
+  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (i >= M) return;
+  const int* sidx = sorted_idx + (size_t)nc * cap;
+  const float* bn = boxes + (size_t)n * P * 6;
+  float bi[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) bi[k] = bn[(size_t)sidx[i] * 6 + k];
+  for (int w = 0; w < Wn; ++w) {
+    const int j = w * 64 + lane;
+    bool over = false;
+    if (j < M) {
+      float bj[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) bj[k] = bn[(size_t)sidx[j] * 6 + k];
+      over = iou6(bi, bj) > max_overlap;  // strict; NaN -> false (ssd3d.py:422)
+    }
+    const unsigned long long bits = __ballot(over);
+    if (lane == 0) mask[((size_t)nc * cap + i) * Wn + w] = bits;
+  }
+}
+
+// one wave per (n, class).  keep word w lives in lane w.
+__global__ __launch_bounds__(64) void detect_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                         const int* __restrict__ ncand, int cap, int Wn,
+                                                         unsigned long long* __restrict__ keep_bits,
+                                                         int* __restrict__ nkept) {
+  const int nc = blockIdx.x, lane = threadIdx.x;
+  const int M = min(ncand[nc], cap);
+  const unsigned long long* mk = mask + (size_t)nc * cap * Wn;
+  unsigned long long supp = 0ull;
+  for (int i = 0; i < M; ++i) {
+    const unsigned long long row = lane < Wn ? mk[(size_t)i * Wn + lane] : 0ull;  // independent of the scan state
+    const unsigned long long wi = __shfl(supp, i >> 6, 64);
+    if (!((wi >> (i & 63)) & 1ull)) {  // wave-uniform
+      supp |= row;                                              // ssd3d.py:422
+      if (lane == (i >> 6)) supp &= ~(1ull << (i & 63));       // ssd3d.py:426
+    }
+  }
+  // keep = ~suppress over [0, M)
+  unsigned long long keep = ~supp;
+  const int base = lane * 64;
+  if (base >= M) keep = 0ull;
+  else if (M - base < 64) keep &= (1ull << (M - base)) - 1ull;
+  if (lane < Wn) keep_bits[(size_t)nc * Wn + lane] = keep;
+  int cnt = __popcll(keep);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
+  if (lane == 0) nkept[nc] = cnt;
+}
+
+// one workgroup per image
+__global__ __launch_bounds__(256) void detect_finalize_kernel(const float* __restrict__ probs,
+                                                              const float* __restrict__ boxes,
+                                                              const int* __restrict__ sorted_idx,
+                                                              const unsigned long long* __restrict__ keep_bits,
+                                                              const int* __restrict__ nkept, int P, int cap, int Wn,
+                                                              int ncls1, int top_k, float* __restrict__ out_boxes,
+                                                              float* __restrict__ out_scores,
+                                                              long long* __restrict__ out_labels,
+                                                              long long* __restrict__ out_prior,
+                                                              int* __restrict__ out_count,
+                                                              float* __restrict__ tmp_scores, int* __restrict__ tmp_ref) {
+  const int n = blockIdx.x;
+  // 1. concat kept candidates of all classes, class-major, each class in score order
+  int offs = 0;
+  const int cat_cap = ncls1 * cap;
+  float* ts = tmp_scores + (size_t)n * cat_cap;
+  int* tr = tmp_ref + (size_t)n * cat_cap;  // class * P + prior
+  for (int c = 0; c < ncls1; ++c) {
+    const int nc = n * ncls1 + c;
+    const unsigned long long* kb = keep_bits + (size_t)nc * Wn;
+    for (int i = threadIdx.x; i < Wn * 64; i += 256) {
+      const unsigned long long word = kb[i >> 6];
+      if ((word >> (i & 63)) & 1ull) {
+        int pos = __popcll(word & ((1ull << (i & 63)) - 1ull));
+        for (int w = 0; w < (i >> 6); ++w) pos += __popcll(kb[w]);
+        const int prior = sorted_idx[(size_t)nc * cap + i];
+        ts[offs + pos] = probs[(size_t)nc * P + prior];
+        tr[offs + pos] = c * P + prior;
+      }
+    }
+    offs += nkept[nc];
+  }
+  __syncthreads();
+  const int total = offs;
+  float* ob = out_boxes + (size_t)n * top_k * 6;
+  float* os = out_scores + (size_t)n * top_k;
+  long long* ol = out_labels + (size_t)n * top_k;
+  long long* op = out_prior + (size_t)n * top_k;
+  if (total == 0) {  // ssd3d.py:437-440
+    if (threadIdx.x == 0) {
+      ob[0] = 0.f; ob[1] = 0.f; ob[2] = 0.f; ob[3] = 1.f; ob[4] = 1.f; ob[5] = 1.f;
+      os[0] = 0.f;
+      ol[0] = 0;
+      op[0] = -1;
+      out_count[n] = 1;
+    }
+    return;
+  }
+  const bool resort = total > top_k;  // ssd3d.py:449-453: stable descending sort, keep top_k
+  for (int i = threadIdx.x; i < total; i += 256) {
+    int pos = i;
+    if (resort) {
+      const float si = ts[i];
+      pos = 0;
+      for (int j = 0; j < total; ++j) {
+        const float sj = ts[j];
+        pos += (sj > si) || (sj == si && j < i);
+      }
+    }
+    if (pos < top_k) {
+      const int ref = tr[i], c = ref / P, prior = ref % P;
+      os[pos] = ts[i];
+      ol[pos] = c + 1;
+      op[pos] = prior;
+#pragma unroll
+      for (int k = 0; k < 6; ++k) ob[pos * 6 + k] = boxes[((size_t)n * P + prior) * 6 + k];
+    }
+  }
+  if (threadIdx.x == 0) out_count[n] = min(total, top_k);
+}
+
+}  // namespace
+
+extern "C" {
+
+// Workspace tensors are caller-allocated (shapes in include/mslesions3d_hip.h).  cap = 10 * top_k <= 4096.
+int msl_detect_objects(const float* locs, const float* scores, const float* priors_c, int N, int P, int ncls,
+                       float min_score, float max_overlap, int top_k, float* probs, float* boxes,
+                       int* sorted_idx, int* ncand, unsigned long long* mask, unsigned long long* keep_bits,
+                       int* nkept, float* tmp_scores, int* tmp_ref, float* out_boxes, float* out_scores,
+                       long long* out_labels, long long* out_prior, int* out_count, void* stream) {
+  if (N <= 0 || P <= 0 || ncls < 2 || top_k < 1) return MSL_ERR_ARG;
+  const int cap = 10 * top_k;
+  if (cap > 4096) return MSL_ERR_UNSUPPORTED;
+  const int Wn = msl::cdiv(cap, 64), ncls1 = ncls - 1;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int) * N * ncls1, st);
+  if (e != hipSuccess) return (int)e;
+  hipLaunchKernelGGL(detect_prepare_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores, priors_c, probs, boxes, N, P, ncls);
+  MSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(detect_rank_kernel, dim3(msl::cdiv(P, 256), N * ncls1), dim3(256), 0, st, probs, min_score, P, cap, sorted_idx, ncand);
+  MSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(detect_mask_kernel, dim3(msl::cdiv(cap, 4), N * ncls1), dim3(256), 0, st, boxes, sorted_idx, ncand, max_overlap, P, cap, Wn, ncls1, mask);
+  MSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(detect_scan_kernel, dim3(N * ncls1), dim3(64), 0, st, mask, ncand, cap, Wn, keep_bits, nkept);
+  MSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(detect_finalize_kernel, dim3(N), dim3(256), 0, st, probs, boxes, sorted_idx, keep_bits, nkept, P, cap, Wn, ncls1, top_k, out_boxes, out_scores, out_labels, out_prior, out_count, tmp_scores, tmp_ref);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+}  // extern "C"

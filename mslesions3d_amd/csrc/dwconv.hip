@@ -1,0 +1,606 @@
+// Depthwise Conv3d(C, C, k3, stride s in {1,2}, pad 1, groups=C, no bias) — forward.
+// Reference: Block.conv1 (lesions3d/mobilenet.py:38,44).  Layout NCDHW fp32, W fastest.
+//
+// The input is the RAW output of the previous conv; its BatchNorm+ReLU is applied while loading
+// (relu(fma(x, scale[c], shift[c]))), so the normalised activation never exists in HBM.  The kernel
+// also emits fp64 (sum, sumsq) partials of its own raw output for the following BatchNorm.
+//
+// Two MI355X shapes of the same algorithm (HBM-bound: ~1.5-6.7 flop/B):
+//  * "stream" (large H x W planes, e.g. 64^2 at 128^3): a workgroup owns a slab of output planes of one
+//    (n, c) volume.  Input planes are streamed once through LDS (16-B coalesced global loads along W,
+//    next plane prefetched into registers while the current one is consumed), each thread keeps the
+//    rolling accumulators of 4 adjacent outputs along W.  For stride 2 the LDS rows are stored
+//    de-interleaved (even | odd columns) so the stride-2 taps become conflict-free 16-B LDS reads.
+//  * "resident" (small planes): the whole input slab (+halo) sits in LDS, one load phase, one compute phase.
+// Workgroup ids are remapped so that the slabs of one volume (which share halo planes) land on the same
+// XCD back to back (per-XCD L2).
+#include "common.hpp"
+#include <algorithm>
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// LDS row geometry
+//   stride 1: [ 3 unused | x[-1]=0 | x[0..W) | x[W]=0 | pad ]      x[iw] at column 4+iw, RS = W + 8
+//   stride 2: [ E[0..EW) | O[0..OQ) ]  E[j] = x[2j],  O[j] = x[2j-1] (O[0] = x[-1] = 0)
+//             EW = roundup4(OW), OQ = roundup4(OW+1), RS = EW + OQ
+template <int STRIDE>
+__device__ __forceinline__ int row_stride(int W, int OW) {
+  if (STRIDE == 1) return W + 8;
+  return ((OW + 3) & ~3) + ((OW + 4) & ~3);
+}
+
+template <int STRIDE>
+__device__ __forceinline__ void store_row4(float* row, int iw, int EW, float v0, float v1, float v2, float v3) {
+  if (STRIDE == 1) {
+    *reinterpret_cast<float4*>(row + 4 + iw) = make_float4(v0, v1, v2, v3);
+  } else {
+    const int j = iw >> 1;  // iw % 4 == 0
+    *reinterpret_cast<float2*>(row + j) = make_float2(v0, v2);  // E[j], E[j+1]
+    row[EW + j + 1] = v1;                                        // O[j+1] = x[2j+1]
+    row[EW + j + 2] = v3;                                        // O[j+2] = x[2j+3]
+  }
+}
+
+// the 6 (stride 1) / 9 (stride 2) input values of one LDS row that feed outputs ow..ow+3
+template <int STRIDE>
+struct RowTaps {
+  float v[3][4];  // v[kw][out]
+  __device__ __forceinline__ void load(const float* row, int ow, int EW) {
+    if (STRIDE == 1) {
+      const float4 m = *reinterpret_cast<const float4*>(row + 4 + ow);
+      const float l = row[3 + ow], r = row[8 + ow];
+      v[0][0] = l;   v[0][1] = m.x; v[0][2] = m.y; v[0][3] = m.z;
+      v[1][0] = m.x; v[1][1] = m.y; v[1][2] = m.z; v[1][3] = m.w;
+      v[2][0] = m.y; v[2][1] = m.z; v[2][2] = m.w; v[2][3] = r;
+    } else {
+      const float4 e = *reinterpret_cast<const float4*>(row + ow);
+      const float4 o = *reinterpret_cast<const float4*>(row + EW + ow);
+      const float o4 = row[EW + ow + 4];
+      v[0][0] = o.x; v[0][1] = o.y; v[0][2] = o.z; v[0][3] = o.w;
+      v[1][0] = e.x; v[1][1] = e.y; v[1][2] = e.z; v[1][3] = e.w;
+      v[2][0] = o.y; v[2][1] = o.z; v[2][2] = o.w; v[2][3] = o4;
+    }
+  }
+};
+
+__device__ __forceinline__ int xcd_remap(int b, int total) {
+  // blocks b and b+8 share an XCD; give each XCD a contiguous range of logical ids
+  return (total & 7) == 0 ? (b & 7) * (total >> 3) + (b >> 3) : b;
+}
+
+// Segmented per-channel reduction of per-item (sum, sumsq) held in LDS, fixed order.
+__device__ __forceinline__ void emit_stats(const float* it_s, const float* it_q, int G, int L, int c0,
+                                           int Ctot, double* partials, int NP, int p) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  for (int g = wv; g < G; g += nw) {
+    double s = 0.0, q = 0.0;
+    for (int i = lane; i < L; i += 64) {
+      s += (double)it_s[g * L + i];
+      q += (double)it_q[g * L + i];
+    }
+    s = msl::wave_sum(s);
+    q = msl::wave_sum(q);
+    if (lane == 0) {
+      partials[(size_t)(c0 + g) * NP + p] = s;
+      partials[((size_t)Ctot + c0 + g) * NP + p] = q;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// "stream" variant.  Workgroup = (n, c, slab of SLAB output planes); the channel is workgroup-uniform, so
+// weights and the input affine live in SGPRs.  IPT items per thread (item = 4 adjacent outputs along W of
+// one output row); LPT float4 prefetch registers per thread.
+template <int STRIDE, int IPT, int LPT>
+__global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int H,
+    int W, int OD, int OH, int OW, int SLAB, int nslabs, int Nbatch) {
+  extern __shared__ __align__(16) float lds[];
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int slab = lb % nslabs;
+  const int nc = lb / nslabs;  // n * C + c
+  const int n = nc / C, c = nc % C;
+  const int od0 = slab * SLAB, od1 = min(OD, od0 + SLAB);
+
+  const int RS = row_stride<STRIDE>(W, OW);
+  const int EW = (OW + 3) & ~3;
+  const int PS = (H + 2) * RS;
+  const int OWV = OW >> 2;
+  const int nitems = OH * OWV;
+  const int W4 = W >> 2;
+  const int tot4 = H * W4;  // float4 per input plane
+
+  const bool affine = in_scale != nullptr;
+  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+  float wk[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = w[c * 27 + k];  // uniform -> scalar registers
+
+  // zero the tile once: halo rows/columns are never written again
+  for (int i = threadIdx.x; i < PS; i += 256) lds[i] = 0.f;
+
+  int it_lds[IPT], it_out[IPT];
+  bool it_ok[IPT];
+#pragma unroll
+  for (int t = 0; t < IPT; ++t) {
+    const int item = threadIdx.x + t * 256;
+    it_ok[t] = item < nitems;
+    const int it = it_ok[t] ? item : 0;
+    const int oh = it / OWV, ow = (it % OWV) * 4;
+    it_lds[t] = (STRIDE * oh) * RS + ow;
+    it_out[t] = oh * OW + ow;
+  }
+
+  float acc_a[IPT][4], acc_b[IPT][4];  // stride 2: a = current od.  stride 1: a = od p-1, b = od p
+  float st_s[IPT], st_q[IPT];
+#pragma unroll
+  for (int t = 0; t < IPT; ++t) {
+    st_s[t] = st_q[t] = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc_a[t][v] = acc_b[t][v] = 0.f;
+  }
+
+  const int p_begin = STRIDE == 2 ? 2 * od0 - 1 : od0 - 1;
+  const int p_end = STRIDE == 2 ? 2 * od1 - 1 : od1;  // inclusive
+
+  // per-prefetch-slot constants (no integer division inside the plane loop)
+  float4 pre[LPT];
+  int gofs[LPT], lofs[LPT];
+  const float* xc = x + (size_t)nc * D * H * W;
+  const size_t plane_elems = (size_t)H * W;
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int q = threadIdx.x + i * 256;
+    const int qq = q < tot4 ? q : 0;
+    const int ih = qq / W4, iw = (qq % W4) * 4;
+    gofs[i] = q < tot4 ? qq * 4 : -1;
+    lofs[i] = (ih + 1) * RS + (STRIDE == 1 ? 4 + iw : (iw >> 1));
+  }
+  auto issue_loads = [&](int p) {
+    if (p < 0 || p >= D) return;
+    const float* xp = xc + (size_t)p * plane_elems;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i)
+      if (gofs[i] >= 0) pre[i] = *reinterpret_cast<const float4*>(xp + gofs[i]);
+  };
+  auto commit_loads = [&](int p) {
+    if (p < 0 || p >= D) return;
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+      if (gofs[i] < 0) continue;
+      float4 v = pre[i];
+      if (affine) {
+        v.x = msl::act(v.x, sc, sh); v.y = msl::act(v.y, sc, sh);
+        v.z = msl::act(v.z, sc, sh); v.w = msl::act(v.w, sc, sh);
+      }
+      float* dst = lds + lofs[i];
+      if (STRIDE == 1) {
+        *reinterpret_cast<float4*>(dst) = v;
+      } else {
+        *reinterpret_cast<float2*>(dst) = make_float2(v.x, v.z);
+        dst[EW + 1] = v.y;
+        dst[EW + 2] = v.w;
+      }
+    }
+  };
+  float* yc = y + (size_t)nc * OD * OH * OW;
+  const int oplane = OH * OW;
+
+  issue_loads(p_begin);
+  for (int p = p_begin; p <= p_end; ++p) {
+    const bool pvalid = p >= 0 && p < D;
+    __syncthreads();  // everyone finished reading the previous plane (and the zero fill on the first trip)
+    commit_loads(p);
+    __syncthreads();
+    if (p < p_end) issue_loads(p + 1);  // in flight while this plane is consumed
+
+    if (STRIDE == 2) {
+      if (p & 1) {
+        const int od_done = (p - 1) >> 1;
+#pragma unroll
+        for (int t = 0; t < IPT; ++t) {
+          if (!it_ok[t]) continue;
+          float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+          if (pvalid) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              RowTaps<2> r;
+              r.load(lds + it_lds[t] + kh * RS, 0, EW);
+#pragma unroll
+              for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) {
+                  acc_a[t][v] = fmaf(wk[18 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
+                  nxt[v] = fmaf(wk[kh * 3 + kw], r.v[kw][v], nxt[v]);
+                }
+            }
+          }
+          if (od_done >= od0) {
+            *reinterpret_cast<float4*>(yc + (size_t)od_done * oplane + it_out[t]) =
+                make_float4(acc_a[t][0], acc_a[t][1], acc_a[t][2], acc_a[t][3]);
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+              st_s[t] += acc_a[t][v];
+              st_q[t] = fmaf(acc_a[t][v], acc_a[t][v], st_q[t]);
+            }
+          }
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc_a[t][v] = nxt[v];
+        }
+      } else if (pvalid) {
+#pragma unroll
+        for (int t = 0; t < IPT; ++t) {
+          if (!it_ok[t]) continue;
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            RowTaps<2> r;
+            r.load(lds + it_lds[t] + kh * RS, 0, EW);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) acc_a[t][v] = fmaf(wk[9 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
+          }
+        }
+      }
+    } else {
+      const int od_done = p - 1;
+#pragma unroll
+      for (int t = 0; t < IPT; ++t) {
+        if (!it_ok[t]) continue;
+        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (pvalid) {
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            RowTaps<1> r;
+            r.load(lds + it_lds[t] + kh * RS, 0, EW);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+#pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                acc_a[t][v] = fmaf(wk[18 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
+                acc_b[t][v] = fmaf(wk[9 + kh * 3 + kw], r.v[kw][v], acc_b[t][v]);
+                nxt[v] = fmaf(wk[kh * 3 + kw], r.v[kw][v], nxt[v]);
+              }
+          }
+        }
+        if (od_done >= od0) {
+          *reinterpret_cast<float4*>(yc + (size_t)od_done * oplane + it_out[t]) =
+              make_float4(acc_a[t][0], acc_a[t][1], acc_a[t][2], acc_a[t][3]);
+#pragma unroll
+          for (int v = 0; v < 4; ++v) {
+            st_s[t] += acc_a[t][v];
+            st_q[t] = fmaf(acc_a[t][v], acc_a[t][v], st_q[t]);
+          }
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          acc_a[t][v] = acc_b[t][v];
+          acc_b[t][v] = nxt[v];
+        }
+      }
+    }
+  }
+
+  if (partials) {
+    __syncthreads();
+    float* it_s = lds;
+    float* it_q = lds + nitems;
+#pragma unroll
+    for (int t = 0; t < IPT; ++t) {
+      const int item = threadIdx.x + t * 256;
+      if (item < nitems) {
+        it_s[item] = st_s[t];
+        it_q[item] = st_q[t];
+      }
+    }
+    __syncthreads();
+    emit_stats(it_s, it_q, 1, nitems, c, C, partials, Nbatch * nslabs, n * nslabs + slab);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// "resident" variant: the whole input slab (+ zero halo) of G channels in LDS.
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int H,
+    int W, int OD, int OH, int OW, int G, int SLAB, int nslabs, int Nbatch) {
+  extern __shared__ __align__(16) float lds[];
+  const int lb = xcd_remap(blockIdx.x, gridDim.x);
+  const int slab = lb % nslabs;
+  const int vg = lb / nslabs;
+  const int CG = C / G;
+  const int n = vg / CG, c0 = (vg % CG) * G;
+  const int od0 = slab * SLAB, od1 = min(OD, od0 + SLAB);
+  const int nod = od1 - od0;
+
+  const int RS = row_stride<STRIDE>(W, OW);
+  const int EW = (OW + 3) & ~3;
+  const int PS = (H + 2) * RS;
+  const int NPL = STRIDE * SLAB + (STRIDE == 2 ? 1 : 2);  // planes kept: stride2: 2*SLAB+1, stride1: SLAB+2
+  const int p0 = STRIDE * od0 - 1;                         // first plane kept
+  const int CS = NPL * PS;                                 // one channel's tile
+  const int OWV = OW >> 2;
+  const int Lp = OH * OWV;        // items per output plane
+  const int L = nod * Lp;         // items per channel in this slab
+  const int nitems = G * L;
+  const int W4 = W >> 2, plane4 = H * W4;
+
+  for (int i = threadIdx.x; i < G * CS; i += 256) lds[i] = 0.f;
+  __syncthreads();
+  const bool affine = in_scale != nullptr;
+  const int tot4 = G * NPL * plane4;
+  for (int q = threadIdx.x; q < tot4; q += 256) {
+    const int g = q / (NPL * plane4);
+    const int r1 = q % (NPL * plane4);
+    const int pl = r1 / plane4, rem = r1 % plane4;
+    const int p = p0 + pl;
+    if (p < 0 || p >= D) continue;
+    const int ih = rem / W4, iw = (rem % W4) * 4;
+    float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * C + c0 + g) * D + p) * H * W + (size_t)rem * 4);
+    if (affine) {
+      const float sc = in_scale[c0 + g], sh = in_shift[c0 + g];
+      v.x = msl::act(v.x, sc, sh); v.y = msl::act(v.y, sc, sh);
+      v.z = msl::act(v.z, sc, sh); v.w = msl::act(v.w, sc, sh);
+    }
+    store_row4<STRIDE>(lds + g * CS + pl * PS + (ih + 1) * RS, iw, EW, v.x, v.y, v.z, v.w);
+  }
+  __syncthreads();
+
+  // stats scratch lives after the tile
+  float* it_s = lds + G * CS;
+  float* it_q = it_s + nitems;
+  for (int item = threadIdx.x; item < nitems; item += 256) {
+    const int g = item / L, r0 = item % L;
+    const int odl = r0 / Lp, r1 = r0 % Lp;
+    const int oh = r1 / OWV, ow = (r1 % OWV) * 4;
+    const float* wc = w + (size_t)(c0 + g) * 27;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const float* base = lds + g * CS + (STRIDE * odl + kd) * PS + (STRIDE * oh) * RS;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh) {
+        RowTaps<STRIDE> r;
+        r.load(base + kh * RS, ow, EW);
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float ww = wc[kd * 9 + kh * 3 + kw];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[v] = fmaf(ww, r.v[kw][v], acc[v]);
+        }
+      }
+    }
+    float* yo = y + ((((size_t)n * C + c0 + g) * OD + od0 + odl) * OH + oh) * OW + ow;
+    *reinterpret_cast<float4*>(yo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      s += acc[v];
+      q = fmaf(acc[v], acc[v], q);
+    }
+    it_s[item] = s;
+    it_q[item] = q;
+  }
+  if (partials) {
+    __syncthreads();
+    emit_stats(it_s, it_q, G, L, c0, C, partials, Nbatch * nslabs, n * nslabs + slab);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Generic fallback (any W, any plane size): one output per thread straight from global memory.
+__global__ __launch_bounds__(256) void dw_fwd_naive_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ w, float* __restrict__ y, int C, int D, int H, int W, int OD, int OH, int OW,
+    int stride) {
+  const int nc = blockIdx.y, c = nc % C;
+  const int OS = OD * OH * OW;
+  const bool affine = in_scale != nullptr;
+  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+  const float* xc = x + (size_t)nc * D * H * W;
+  for (int o = blockIdx.x * 256 + threadIdx.x; o < OS; o += gridDim.x * 256) {
+    const int ow = o % OW, oh = (o / OW) % OH, od = o / (OW * OH);
+    float acc = 0.f;
+    for (int kd = 0; kd < 3; ++kd) {
+      const int id = od * stride - 1 + kd;
+      if (id < 0 || id >= D) continue;
+      for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * stride - 1 + kh;
+        if (ih < 0 || ih >= H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+          const int iw = ow * stride - 1 + kw;
+          if (iw < 0 || iw >= W) continue;
+          float v = xc[((size_t)id * H + ih) * W + iw];
+          if (affine) v = msl::act(v, sc, sh);
+          acc = fmaf(w[c * 27 + kd * 9 + kh * 3 + kw], v, acc);
+        }
+      }
+    }
+    y[(size_t)nc * OS + o] = acc;
+  }
+}
+
+constexpr int STATS_CHUNK = 4096;
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ y,
+                                                            double* __restrict__ partials, int C, int S,
+                                                            int chunks) {
+  __shared__ double scratch[8];
+  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const size_t base = ((size_t)n * C + c) * S;
+  const int lo = chunk * STATS_CHUNK, hi = min(S, lo + STATS_CHUNK);
+  float s = 0.f, q = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = y[base + i];
+    s += v;
+    q = fmaf(v, v, q);
+  }
+  const int NP = gridDim.z * chunks, p = n * chunks + chunk;
+  const double t1 = msl::block_sum((double)s, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum((double)q, scratch);
+  if (threadIdx.x == 0) {
+    partials[(size_t)c * NP + p] = t1;
+    partials[((size_t)C + c) * NP + p] = t2;
+  }
+}
+
+struct DwPlan {
+  int variant;  // 0 naive, 1 stream, 2 resident
+  int G, SLAB, nslabs, ipt, lpt;
+  size_t lds_bytes;
+  int num_partials;
+};
+
+inline int pow2_floor(int v) {
+  int p = 1;
+  while (p * 2 <= v) p *= 2;
+  return p;
+}
+
+DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
+  DwPlan pl{};
+  const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const bool fast = (W % 4 == 0) && (OW % 4 == 0) && (stride == 1 || (H % 2 == 0 && W % 2 == 0));
+  const int S = OD * OH * OW;
+  if (!fast) {
+    pl.variant = 0;
+    pl.num_partials = N * msl::cdiv(S, STATS_CHUNK);
+    return pl;
+  }
+  const int RS = stride == 1 ? W + 8 : ((OW + 3) & ~3) + ((OW + 4) & ~3);
+  const int PS = (H + 2) * RS;
+  const int OWV = OW / 4, Lp = OH * OWV;
+  if (H * W > 1024) {  // stream
+    int G = 1;
+    int ipt = msl::cdiv(G * Lp, 256);
+    int lpt = msl::cdiv(G * H * (W / 4), 256);
+    size_t lds = (size_t)G * PS * 4;
+    lds = lds > (size_t)2 * G * Lp * 4 ? lds : (size_t)2 * G * Lp * 4;
+    if (ipt > 4 || lpt > 12 || lds > 160 * 1024) {
+      pl.variant = 0;
+      pl.num_partials = N * msl::cdiv(S, STATS_CHUNK);
+      return pl;
+    }
+    pl.variant = 1;
+    pl.G = G;
+    pl.ipt = ipt <= 1 ? 1 : 4;
+    pl.lpt = lpt <= 4 ? 4 : 12;
+    const int nvol = N * (C / G);
+    int slabs = std::max(1, std::min(OD, 1024 / std::max(1, nvol)));
+    int SLAB = msl::cdiv(OD, slabs);
+    if (SLAB < 4) SLAB = std::min(4, OD);
+    pl.SLAB = SLAB;
+    pl.nslabs = msl::cdiv(OD, SLAB);
+    pl.lds_bytes = lds;
+    pl.num_partials = N * pl.nslabs;
+    return pl;
+  }
+  // resident: choose SLAB (power of two dividing work) and G so that ~256..1024 items and <= 60 KB of LDS
+  int SLAB = OD;
+  const int nvol1 = N * C;
+  while (SLAB > 2 && (nvol1 * msl::cdiv(OD, SLAB) < 1024 || (size_t)(stride * SLAB + 2) * PS * 4 > 40 * 1024) &&
+         SLAB % 2 == 0 && SLAB / 2 >= 2)
+    SLAB /= 2;
+  int NPL = stride * SLAB + (stride == 2 ? 1 : 2);
+  size_t per_ch = (size_t)NPL * PS * 4 + (size_t)2 * SLAB * Lp * 4;
+  if (per_ch > 160 * 1024) {
+    pl.variant = 0;
+    pl.num_partials = N * msl::cdiv(S, STATS_CHUNK);
+    return pl;
+  }
+  int G = std::max(1, 256 / std::max(1, SLAB * Lp));
+  G = pow2_floor(G);
+  while (G > 1 && (C % G != 0 || per_ch * G > 60 * 1024)) G /= 2;
+  pl.variant = 2;
+  pl.G = G;
+  pl.SLAB = SLAB;
+  pl.nslabs = msl::cdiv(OD, SLAB);
+  pl.lds_bytes = per_ch * G;
+  pl.num_partials = N * pl.nslabs;
+  return pl;
+}
+
+template <typename K>
+int set_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride) {
+  return make_plan(N, C, D, H, W, stride).num_partials;
+}
+
+// variant actually chosen for a shape (0 naive, 1 stream, 2 resident) — for tests / DESIGN.md
+int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride) {
+  return make_plan(N, C, D, H, W, stride).variant;
+}
+
+int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                   double* partials, int N, int C, int D, int H, int W, int stride, int force_naive,
+                   void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
+  const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  DwPlan pl = make_plan(N, C, D, H, W, stride);
+  hipStream_t st = (hipStream_t)stream;
+  if (force_naive && pl.variant != 0) {
+    pl.variant = 0;
+    pl.num_partials = N * msl::cdiv(OD * OH * OW, STATS_CHUNK);
+  }
+  if (pl.variant == 0) {
+    const int S = OD * OH * OW;
+    hipLaunchKernelGGL(dw_fwd_naive_kernel, dim3(std::min(msl::cdiv(S, 256), 256), N * C), dim3(256), 0, st, x,
+                       in_scale, in_shift, w, y, C, D, H, W, OD, OH, OW, stride);
+    MSL_LAUNCH_CHECK();
+    if (partials) {
+      const int chunks = msl::cdiv(S, STATS_CHUNK);
+      hipLaunchKernelGGL(channel_stats_kernel, dim3(chunks, C, N), dim3(256), 0, st, y, partials, C, S, chunks);
+      MSL_LAUNCH_CHECK();
+    }
+    return MSL_OK;
+  }
+  const int nblocks = N * (C / pl.G) * pl.nslabs;
+  if (pl.variant == 1) {
+#define MSL_DW_STREAM(S_, I_, L_)                                                                              \
+  do {                                                                                                         \
+    int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_>, pl.lds_bytes);                                          \
+    if (e_) return e_;                                                                                         \
+    hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x,      \
+                       in_scale, in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N);        \
+  } while (0)
+    if (stride == 2) {
+      if (pl.ipt == 1 && pl.lpt == 4) MSL_DW_STREAM(2, 1, 4);
+      else MSL_DW_STREAM(2, 4, 12);
+    } else {
+      if (pl.ipt == 1 && pl.lpt == 4) MSL_DW_STREAM(1, 1, 4);
+      else MSL_DW_STREAM(1, 4, 12);
+    }
+#undef MSL_DW_STREAM
+  } else {
+    if (stride == 2) {
+      int e_ = set_lds(dw_fwd_resident_kernel<2>, pl.lds_bytes);
+      if (e_) return e_;
+      hipLaunchKernelGGL(dw_fwd_resident_kernel<2>, dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
+                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N);
+    } else {
+      int e_ = set_lds(dw_fwd_resident_kernel<1>, pl.lds_bytes);
+      if (e_) return e_;
+      hipLaunchKernelGGL(dw_fwd_resident_kernel<1>, dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
+                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N);
+    }
+  }
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,477 @@
+// SSD detection heads: per scale, Conv3d(C -> 12, k3, p1, bias) (box offsets, 2 anchors x 6) and
+// Conv3d(C -> 2*n_classes, k3, p1, bias) (class scores), followed in the reference by
+// permute(0,2,3,4,1).contiguous().view(N,-1,6|n_classes) and a concat over scales.
+// Reference: PredictionConvolutions (lesions3d/ssd3d.py:113-169).
+//
+// Here both convolutions of a scale are ONE implicit GEMM (M = 12 + 2*n_classes output channels padded to
+// 16, K = C*27, N = positions) on v_mfma_f32_16x16x4_f32, sharing a single read of the feature map, and
+// the epilogue writes straight into the final (N, P, 6) / (N, P, n_classes) rows at the scale's prior
+// offset: the permute, the .contiguous() copy and the concat never happen.
+// The feature map is read from a zero-haloed copy (N, C, D+2, H+2, W+2), so the 27 taps are plain
+// address offsets with no bounds tests.  Weights are pre-packed into MFMA fragment order (one coalesced
+// 256-B load per fragment).  K is split over the 4 waves of a workgroup (and over workgroups for the
+// small, channel-heavy scales) with a fixed-order reduction.
+#include "common.hpp"
+#include <algorithm>
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ---- weight packing ---------------------------------------------------------------------------
+// forward fragments: Wf[((cg*27 + tap)*MT + mt)*64 + lane] = Wall[co = mt*16 + (lane&15)][ci = 4*cg + (lane>>4)][tap]
+// bwd-data fragments: Wb[(((ct*(4*MT) + cog)*27) + tap)*64 + lane] = Wall[co = 4*cog + (lane>>4)][ci = 16*ct + (lane&15)][tap]
+__global__ void head_pack_weights_kernel(const float* __restrict__ loc_w, const float* __restrict__ cl_w,
+                                         float* __restrict__ Wf, float* __restrict__ Wb, int C, int co_total,
+                                         int MT) {
+  const int total = C / 4 * 27 * MT * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    {
+      const int lane = i & 63;
+      int r = i >> 6;
+      const int mt = r % MT;
+      r /= MT;
+      const int tap = r % 27, cg = r / 27;
+      const int co = mt * 16 + (lane & 15), ci = 4 * cg + (lane >> 4);
+      float v = 0.f;
+      if (co < 12) v = loc_w[((size_t)co * C + ci) * 27 + tap];
+      else if (co < co_total) v = cl_w[((size_t)(co - 12) * C + ci) * 27 + tap];
+      Wf[i] = v;
+    }
+    {
+      const int lane = i & 63;
+      int r = i >> 6;
+      const int tap = r % 27;
+      r /= 27;
+      const int cog = r % (4 * MT), ct = r / (4 * MT);
+      const int co = 4 * cog + (lane >> 4), ci = 16 * ct + (lane & 15);
+      float v = 0.f;
+      if (co < 12) v = loc_w[((size_t)co * C + ci) * 27 + tap];
+      else if (co < co_total) v = cl_w[((size_t)(co - 12) * C + ci) * 27 + tap];
+      Wb[i] = v;
+    }
+  }
+}
+
+__device__ __forceinline__ void write_head_outputs(const f32x4 v, int mt, int q, int n, int P, int S,
+                                                   const float* loc_b, const float* cl_b, float* locs,
+                                                   float* scores, int Ptot, int prior_off, int ncls,
+                                                   int co_total) {
+  if (P >= S) return;
+  const size_t lbase = ((size_t)n * Ptot + prior_off) * 6 + (size_t)P * 12;
+  const size_t sbase = ((size_t)n * Ptot + prior_off) * ncls + (size_t)P * 2 * ncls;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int co = mt * 16 + 4 * q + r;
+    if (co < 12) locs[lbase + co] = v[r] + loc_b[co];
+    else if (co < co_total) scores[sbase + co - 12] = v[r] + cl_b[co - 12];
+  }
+}
+
+// ---- forward ------------------------------------------------------------------------------------
+// grid (ceil(S/32), N, KSG); block 256 = 4 waves, each wave a quarter of this block's channel range.
+template <int MT>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ a_pad,
+                                                       const float* __restrict__ Wf,
+                                                       const float* __restrict__ loc_b,
+                                                       const float* __restrict__ cl_b, float* __restrict__ locs,
+                                                       float* __restrict__ scores, float* __restrict__ slabs,
+                                                       int C, int D, int H, int W, int Ptot, int prior_off,
+                                                       int ncls, int co_total, int KSG) {
+  __shared__ f32x4 red[4][2][MT][64];
+  const int n = blockIdx.y, ksg = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int S = D * H * W, Hp = H + 2, Wp = W + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Wp;
+  const int p0 = blockIdx.x * 32;
+  const int cpw = C / (4 * KSG);          // channels per wave
+  const int cbase = (ksg * 4 + wv) * cpw;  // first channel of this wave
+
+  int boff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int P = p0 + t * 16 + j;
+    if (P >= S) P = S - 1;
+    const int w = P % W, h = (P / W) % H, d = P / (W * H);
+    boff[t] = (d * Hp + h) * Wp + w;
+  }
+  const float* ap = a_pad + ((size_t)n * C + cbase + q) * volp;
+  const float* wp = Wf + (size_t)(cbase / 4) * 27 * MT * 64 + lane;
+
+  f32x4 acc[2][MT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) acc[t][m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int cg = 0; cg < cpw / 4; ++cg) {
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = kd * 9 + kh * 3 + kw;
+          const int toff = (kd * Hp + kh) * Wp + kw;
+          const float b0 = ap[boff[0] + toff];
+          const float b1 = ap[boff[1] + toff];
+#pragma unroll
+          for (int m = 0; m < MT; ++m) {
+            const float a = wp[(size_t)(tap * MT + m) * 64];
+            acc[0][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc[0][m], 0, 0, 0);
+            acc[1][m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc[1][m], 0, 0, 0);
+          }
+        }
+    ap += 4 * volp;
+    wp += (size_t)27 * MT * 64;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int m = 0; m < MT; ++m) red[wv][t][m][lane] = acc[t][m];
+  __syncthreads();
+  // (tile, mt) pairs are finalised by waves 0 .. 2*MT-1; fixed summation order over the 4 k-split waves
+  for (int pair = wv; pair < 2 * MT; pair += 4) {
+    const int t = pair / MT, m = pair % MT;
+    f32x4 s = red[0][t][m][lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) s += red[w2][t][m][lane];
+    const int P = p0 + t * 16 + j;
+    if (KSG == 1) {
+      write_head_outputs(s, m, q, n, P, S, loc_b, cl_b, locs, scores, Ptot, prior_off, ncls, co_total);
+    } else if (P < S) {
+      // slabs[ksg][n][P][16*MT]
+      float* dst = slabs + (((size_t)ksg * gridDim.y + n) * S + P) * (16 * MT) + m * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(dst) = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_finalize_kernel(const float* __restrict__ slabs,
+                                                                const float* __restrict__ loc_b,
+                                                                const float* __restrict__ cl_b,
+                                                                float* __restrict__ locs, float* __restrict__ scores,
+                                                                int N, int S, int MT, int KSG, int Ptot,
+                                                                int prior_off, int ncls, int co_total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;  // over N*S*(4*MT) quads
+  const int quads = 4 * MT;
+  if (i >= N * S * quads) return;
+  const int qd = i % quads, P = (i / quads) % S, n = i / (quads * S);
+  f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < KSG; ++k)
+    s += *reinterpret_cast<const f32x4*>(slabs + (((size_t)k * N + n) * S + P) * (16 * MT) + qd * 4);
+  write_head_outputs(s, qd / 4, qd % 4, n, P, S, loc_b, cl_b, locs, scores, Ptot, prior_off, ncls, co_total);
+}
+
+// ---- backward -----------------------------------------------------------------------------------
+// dO_pad (N, 16*MT, D+2, H+2, W+2): channel-major, zero halo, zero for padded channels.
+__global__ __launch_bounds__(256) void head_grad_pack_kernel(const float* __restrict__ dlocs,
+                                                             const float* __restrict__ dscores,
+                                                             float* __restrict__ dO_pad, int N, int D, int H, int W,
+                                                             int CO, int Ptot, int prior_off, int ncls,
+                                                             int co_total) {
+  const int S = D * H * W, Hp = H + 2, Wp = W + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Wp;
+  const int total = N * CO * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int P = i % S, co = (i / S) % CO, n = i / (S * CO);
+    float v = 0.f;
+    if (co < 12) v = dlocs[((size_t)n * Ptot + prior_off) * 6 + (size_t)P * 12 + co];
+    else if (co < co_total) v = dscores[((size_t)n * Ptot + prior_off) * ncls + (size_t)P * 2 * ncls + co - 12];
+    const int w = P % W, h = (P / W) % H, d = P / (W * H);
+    dO_pad[((size_t)n * CO + co) * volp + ((size_t)(d + 1) * Hp + h + 1) * Wp + w + 1] = v;
+  }
+}
+
+// g_a (N, C, S) = conv_transpose(dO, W).  grid (ceil(S/32), C/64, N); wave -> 16 input channels x 32 positions
+template <int MT>
+__global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ dO_pad,
+                                                            const float* __restrict__ Wb, float* __restrict__ g_a,
+                                                            int C, int D, int H, int W) {
+  const int n = blockIdx.z;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int S = D * H * W, Hp = H + 2, Wp = W + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Wp;
+  const int p0 = blockIdx.x * 32;
+  const int ct = blockIdx.y * 4 + wv;  // 16-channel tile
+  if (ct * 16 >= C) return;
+  constexpr int COG = 4 * MT;
+
+  int boff[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int P = p0 + t * 16 + j;
+    if (P >= S) P = S - 1;
+    const int w = P % W, h = (P / W) % H, d = P / (W * H);
+    boff[t] = (d * Hp + h) * Wp + w;
+  }
+  const float* dp = dO_pad + ((size_t)n * 16 * MT + q) * volp;
+  const float* wp = Wb + (size_t)ct * COG * 27 * 64 + lane;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+  for (int cog = 0; cog < COG; ++cog) {
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = kd * 9 + kh * 3 + kw;
+          const int toff = ((2 - kd) * Hp + (2 - kh)) * Wp + (2 - kw);
+          const float a = wp[(size_t)tap * 64];
+          const float b0 = dp[boff[0] + toff];
+          const float b1 = dp[boff[1] + toff];
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b0, acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b1, acc1, 0, 0, 0);
+        }
+    dp += 4 * volp;
+    wp += (size_t)27 * 64;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int ci = ct * 16 + 4 * q + r;
+    float* dst = g_a + ((size_t)n * C + ci) * S;
+    const int P0 = p0 + j, P1 = p0 + 16 + j;
+    if (P0 < S) dst[P0] = acc0[r];
+    if (P1 < S) dst[P1] = acc1[r];
+  }
+}
+
+// dW slabs.  grid (nchunk_blocks, C/16); block = 4 waves = 4 consecutive position chunks of `steps` MFMA
+// k-steps (4 positions each).  Every wave keeps the 27 tap accumulators (16 co x 16 ci) of its ci tile.
+template <int MT>
+__global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __restrict__ dO_pad,
+                                                              const float* __restrict__ a_pad,
+                                                              float* __restrict__ slabs, int N, int C, int D,
+                                                              int H, int W, int steps) {
+  extern __shared__ __align__(16) float red[];  // [27*MT][256]
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int j = lane & 15, q = lane >> 4;
+  const int S = D * H * W, Hp = H + 2, Wp = W + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Wp;
+  const int total = N * S;
+  const int ct = blockIdx.y;
+  const int chunk = blockIdx.x * 4 + wv;
+  const int pbeg = chunk * steps * 4;
+
+  f32x4 acc[27 * MT];
+#pragma unroll
+  for (int i = 0; i < 27 * MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  for (int s = 0; s < steps; ++s) {
+    int gp = pbeg + s * 4 + q;  // global position index over (n, d, h, w)
+    const bool ok = gp < total;
+    if (!ok) gp = total - 1;
+    const int n = gp / S, P = gp % S;
+    const int w = P % W, h = (P / W) % H, d = P / (W * H);
+    const size_t off = ((size_t)d * Hp + h) * Wp + w;  // tap (0,0,0) corner in padded coordinates
+    float a[MT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m) {
+      const float v = dO_pad[((size_t)n * 16 * MT + m * 16 + j) * volp + off + (size_t)Hp * Wp + Wp + 1];
+      a[m] = ok ? v : 0.f;
+    }
+    const float* bp = a_pad + ((size_t)n * C + ct * 16 + j) * volp + off;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const int tap = kd * 9 + kh * 3 + kw;
+          const float b = bp[(kd * Hp + kh) * Wp + kw];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[tap * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[tap * MT + m], 0, 0, 0);
+        }
+  }
+  // fixed-order reduction over the 4 waves
+  for (int w2 = 3; w2 >= 1; --w2) {
+    if (wv == w2) {
+#pragma unroll
+      for (int i = 0; i < 27 * MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* p = red + ((size_t)i * 4 + r) * 64 + lane;
+          if (w2 == 3) *p = acc[i][r];
+          else *p += acc[i][r];
+        }
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {
+    // slabs[blockIdx.x][ct][tap][mt][co_local 16][ci_local 16]
+    float* out = slabs + ((size_t)blockIdx.x * gridDim.y + ct) * (27 * MT * 256);
+#pragma unroll
+    for (int i = 0; i < 27 * MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(size_t)i * 256 + (4 * q + r) * 16 + j] = acc[i][r] + red[((size_t)i * 4 + r) * 64 + lane];
+  }
+}
+
+// dW[co][ci][tap] = sum over slabs (fixed order); also splits into the loc / cls weight gradients
+__global__ __launch_bounds__(256) void head_bwd_weight_reduce_kernel(const float* __restrict__ slabs,
+                                                                     float* __restrict__ dloc_w,
+                                                                     float* __restrict__ dcl_w, int C, int MT,
+                                                                     int nslabs, int co_total) {
+  const int total = co_total * C * 27;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int tap = i % 27, ci = (i / 27) % C, co = i / (27 * C);
+  const int ct = ci / 16, cil = ci % 16, mt = co / 16, col = co % 16;
+  const int CT = C / 16;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k)
+    s += slabs[((size_t)k * CT + ct) * (27 * MT * 256) + (size_t)(tap * MT + mt) * 256 + col * 16 + cil];
+  if (co < 12) dloc_w[((size_t)co * C + ci) * 27 + tap] = s;
+  else dcl_w[((size_t)(co - 12) * C + ci) * 27 + tap] = s;
+}
+
+// dbias[co] = sum_{n,P} dO[co][P]  (sums the zero halo as well)
+__global__ __launch_bounds__(256) void head_bias_grad_kernel(const float* __restrict__ dO_pad,
+                                                             float* __restrict__ dloc_b, float* __restrict__ dcl_b,
+                                                             int N, int CO, size_t volp) {
+  __shared__ double scratch[8];
+  const int co = blockIdx.x;
+  double s = 0.0;
+  for (int n = 0; n < N; ++n) {
+    const float* p = dO_pad + ((size_t)n * CO + co) * volp;
+    float part = 0.f;
+    for (size_t i = threadIdx.x; i < volp; i += 256) part += p[i];
+    s += (double)part;
+  }
+  const double t = msl::block_sum(s, scratch);
+  if (threadIdx.x == 0) {
+    if (co < 12) dloc_b[co] = (float)t;
+    else dcl_b[co - 12] = (float)t;
+  }
+}
+
+inline int head_mt(int ncls) { return (12 + 2 * ncls + 15) / 16; }
+
+inline int head_ksg(int N, int C, int S) {
+  int blocks = msl::cdiv(S, 32) * N;
+  int ksg = 1;
+  while (blocks * ksg < 256 && C / (4 * ksg * 2) >= 4 && (C % (4 * ksg * 2 * 4)) == 0) ksg *= 2;
+  return ksg;
+}
+
+struct HwPlan {
+  int steps, nblocks;
+};
+inline HwPlan head_bw_plan(int N, int C, int S) {
+  const int total_steps = msl::cdiv(N * S, 4);
+  const int tiles = C / 16;
+  int want_blocks = std::max(1, 512 / tiles);  // blocks along the position axis
+  int steps = std::max(8, msl::cdiv(total_steps, want_blocks * 4));
+  HwPlan p;
+  p.steps = steps;
+  p.nblocks = msl::cdiv(total_steps, steps * 4);
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t msl_head_packed_weight_elems(int C, int ncls) { return (size_t)C / 4 * 27 * head_mt(ncls) * 64; }
+
+int msl_head_pack_weights(const float* loc_w, const float* cl_w, float* Wf, float* Wb, int C, int ncls,
+                          void* stream) {
+  if (C % 16 != 0 || ncls < 1 || head_mt(ncls) > 2) return MSL_ERR_ARG;
+  const int MT = head_mt(ncls);
+  const int total = C / 4 * 27 * MT * 64;
+  hipLaunchKernelGGL(head_pack_weights_kernel, dim3(std::min(msl::cdiv(total, 256), 1024)), dim3(256), 0,
+                     (hipStream_t)stream, loc_w, cl_w, Wf, Wb, C, 12 + 2 * ncls, MT);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+size_t msl_head_fwd_workspace_bytes(int N, int C, int D, int H, int W, int ncls) {
+  const int S = D * H * W, ksg = head_ksg(N, C, S);
+  return ksg > 1 ? (size_t)ksg * N * S * 16 * head_mt(ncls) * sizeof(float) : 0;
+}
+
+// a_pad (N,C,D+2,H+2,W+2) -> rows [prior_off, prior_off + 2*D*H*W) of locs (N,Ptot,6) / scores (N,Ptot,ncls)
+int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, const float* cl_b, float* locs,
+                      float* scores, float* workspace, int N, int C, int D, int H, int W, int Ptot,
+                      int prior_off, int ncls, void* stream) {
+  if (N <= 0 || C % 16 != 0 || D <= 0 || H <= 0 || W <= 0 || ncls < 1 || head_mt(ncls) > 2) return MSL_ERR_ARG;
+  const int S = D * H * W, MT = head_mt(ncls), co_total = 12 + 2 * ncls;
+  const int ksg = head_ksg(N, C, S);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(msl::cdiv(S, 32), N, ksg);
+  if (MT == 1)
+    hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
+  else
+    hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
+  MSL_LAUNCH_CHECK();
+  if (ksg > 1) {
+    const int total = N * S * 4 * MT;
+    hipLaunchKernelGGL(head_fwd_finalize_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, st, workspace, loc_b,
+                       cl_b, locs, scores, N, S, MT, ksg, Ptot, prior_off, ncls, co_total);
+    MSL_LAUNCH_CHECK();
+  }
+  return MSL_OK;
+}
+
+// (dlocs, dscores) rows of this scale -> dO_pad (N, 16*MT, D+2, H+2, W+2); halo must already be zero
+int msl_head_grad_pack(const float* dlocs, const float* dscores, float* dO_pad, int N, int D, int H, int W,
+                       int Ptot, int prior_off, int ncls, void* stream) {
+  const int MT = head_mt(ncls), CO = 16 * MT;
+  const int total = N * CO * D * H * W;
+  hipLaunchKernelGGL(head_grad_pack_kernel, dim3(std::min(msl::cdiv(total, 256), 2048)), dim3(256), 0,
+                     (hipStream_t)stream, dlocs, dscores, dO_pad, N, D, H, W, CO, Ptot, prior_off, ncls,
+                     12 + 2 * ncls);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int N, int C, int D, int H, int W,
+                           int ncls, void* stream) {
+  if (C % 16 != 0) return MSL_ERR_ARG;
+  const int S = D * H * W, MT = head_mt(ncls);
+  dim3 grid(msl::cdiv(S, 32), msl::cdiv(C, 64), N);
+  if (MT == 1) hipLaunchKernelGGL(head_bwd_data_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dO_pad, Wb, g_a, C, D, H, W);
+  else hipLaunchKernelGGL(head_bwd_data_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dO_pad, Wb, g_a, C, D, H, W);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+size_t msl_head_bwd_weight_workspace_bytes(int N, int C, int D, int H, int W, int ncls) {
+  HwPlan p = head_bw_plan(N, C, D * H * W);
+  return (size_t)p.nblocks * (C / 16) * 27 * head_mt(ncls) * 256 * sizeof(float);
+}
+
+int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dloc_w, float* dcl_w,
+                             float* dloc_b, float* dcl_b, float* workspace, int N, int C, int D, int H, int W,
+                             int ncls, void* stream) {
+  if (C % 16 != 0) return MSL_ERR_ARG;
+  const int S = D * H * W, MT = head_mt(ncls), co_total = 12 + 2 * ncls;
+  HwPlan p = head_bw_plan(N, C, S);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(p.nblocks, C / 16);
+  const size_t lds = (size_t)27 * MT * 256 * sizeof(float);
+  if (MT == 1) {
+    hipLaunchKernelGGL(head_bwd_weight_kernel<1>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, N, C, D, H, W, p.steps);
+  } else {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_weight_kernel<2>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(head_bwd_weight_kernel<2>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, N, C, D, H, W, p.steps);
+  }
+  MSL_LAUNCH_CHECK();
+  const int total = co_total * C * 27;
+  hipLaunchKernelGGL(head_bwd_weight_reduce_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, st, workspace,
+                     dloc_w, dcl_w, C, MT, p.nblocks, co_total);
+  MSL_LAUNCH_CHECK();
+  const size_t volp = (size_t)(D + 2) * (H + 2) * (W + 2);
+  hipLaunchKernelGGL(head_bias_grad_kernel, dim3(co_total), dim3(256), 0, st, dO_pad, dloc_b, dcl_b, N, 16 * MT, volp);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+}  // extern "C"

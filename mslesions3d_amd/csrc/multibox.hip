@@ -1,0 +1,423 @@
+// Prior (anchor) generation, box transforms, IoU, prior<->object matching with target encoding, and the
+// MultiBox loss (forward + closed-form backward).
+// Reference: LSSD3D.create_prior_boxes (lesions3d/ssd3d.py:286-342), box utilities
+// (lesions3d/utils.py:42-149), MultiBoxLoss (lesions3d/ssd3d.py:741-941).
+//
+// Everything here is tiny (P = 9344 priors at 128^3) and latency-bound: the ~40 small torch ops + host
+// syncs per image of the reference become 6 launches for the whole batch with no host round trip.
+// Integer outputs (matched object per prior, classes) must be bit-exact, so the IoU arithmetic follows the
+// reference's operation order with FMA contraction disabled, and ties are resolved explicitly:
+// first maximum wins; in the force-match the highest-numbered object wins (last writer, ssd3d.py:865).
+#include "common.hpp"
+#pragma clang fp contract(off)
+
+namespace {
+
+struct Box {
+  float v[6];
+};
+
+__device__ __forceinline__ Box load_box(const float* p) {
+  Box b;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) b.v[i] = p[i];
+  return b;
+}
+
+// utils.py:42-51
+__device__ __forceinline__ Box c_to_xyz(const Box& c) {
+  Box o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float h = c.v[3 + i] / 2.0f;
+    o.v[i] = c.v[i] - h;
+    o.v[3 + i] = c.v[i] + h;
+  }
+  return o;
+}
+// utils.py:92-102
+__device__ __forceinline__ Box xyz_to_c(const Box& b) {
+  Box o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o.v[i] = (b.v[3 + i] + b.v[i]) / 2.0f;
+    o.v[3 + i] = b.v[3 + i] - b.v[i];
+  }
+  return o;
+}
+// utils.py:71-89
+__device__ __forceinline__ Box encode_box(const Box& c, const Box& p) {
+  Box o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o.v[i] = (c.v[i] - p.v[i]) / (p.v[3 + i] / 10.0f);
+    o.v[3 + i] = logf(c.v[3 + i] / p.v[3 + i]) * 5.0f;
+  }
+  return o;
+}
+// utils.py:54-68
+__device__ __forceinline__ Box decode_box(const Box& g, const Box& p) {
+  Box o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    o.v[i] = g.v[i] * p.v[3 + i] / 10.0f + p.v[i];
+    o.v[3 + i] = expf(g.v[3 + i] / 5.0f) * p.v[3 + i];
+  }
+  return o;
+}
+__device__ __forceinline__ float box_vol(const Box& b) {
+  return (b.v[3] - b.v[0]) * (b.v[4] - b.v[1]) * (b.v[5] - b.v[2]);
+}
+// utils.py:105-149
+__device__ __forceinline__ float box_inter(const Box& a, const Box& b) {
+  float e[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float lo = fmaxf(a.v[i], b.v[i]);
+    const float hi = fminf(a.v[3 + i], b.v[3 + i]);
+    e[i] = fmaxf(hi - lo, 0.0f);
+  }
+  return e[0] * e[1] * e[2];
+}
+__device__ __forceinline__ float box_iou(const Box& a, float vol_a, const Box& b, float vol_b) {
+  const float inter = box_inter(a, b);
+  const float uni = vol_a + vol_b - inter;
+  return inter / uni;
+}
+
+// ---- priors -------------------------------------------------------------------------------------
+__global__ void make_priors_kernel(float* __restrict__ out, int row_off, int D0, int D1, int D2, double scale,
+                                   int bpl) {
+  const int total = D0 * D1 * D2 * bpl;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const int b = t % bpl;
+  int r = t / bpl;
+  const int k = r % D2;
+  r /= D2;
+  const int j = r % D1, i = r / D1;
+  const double cx = ((double)j + 0.5) / D1, cy = ((double)i + 0.5) / D0, cz = ((double)k + 0.5) / D2;  // ssd3d.py:307-309
+  const double sz = b == 0 ? scale : scale + scale / (double)b;                                    // ssd3d.py:330-331
+  float* o = out + (size_t)(row_off + t) * 6;
+  const double vals[6] = {cx, cy, cz, sz, sz, sz};
+#pragma unroll
+  for (int q = 0; q < 6; ++q) o[q] = fminf(fmaxf((float)vals[q], 0.0f), 1.0f);  // ssd3d.py:337
+}
+
+// ---- element-wise box transforms (the utils.* API) --------------------------------------------
+__global__ void box_transform_kernel(const float* __restrict__ a, const float* __restrict__ pri, float* __restrict__ out,
+                                     int n, int op) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const Box x = load_box(a + (size_t)i * 6);
+  Box o;
+  if (op == 0) o = c_to_xyz(x);
+  else if (op == 1) o = xyz_to_c(x);
+  else if (op == 2) o = encode_box(x, load_box(pri + (size_t)i * 6));
+  else o = decode_box(x, load_box(pri + (size_t)i * 6));
+#pragma unroll
+  for (int q = 0; q < 6; ++q) out[(size_t)i * 6 + q] = o.v[q];
+}
+
+__global__ void iou_matrix_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out,
+                                  int n1, int n2, int inter_only) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+  if (j >= n2) return;
+  const Box x = load_box(a + (size_t)i * 6), y = load_box(b + (size_t)j * 6);
+  out[(size_t)i * n2 + j] = inter_only ? box_inter(x, y) : box_iou(x, box_vol(x), y, box_vol(y));
+}
+
+// ---- matching -----------------------------------------------------------------------------------
+// best object per prior: first maximum over objects in ascending order (ssd3d.py:801, :833-837)
+__global__ __launch_bounds__(256) void match_prior_best_kernel(const float* __restrict__ gt_boxes,
+                                                               const int* __restrict__ obj_off,
+                                                               const float* __restrict__ priors_c,
+                                                               float* __restrict__ overlap, int* __restrict__ obj,
+                                                               int P) {
+  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const int o0 = obj_off[n], o1 = obj_off[n + 1];
+  const Box pb = c_to_xyz(load_box(priors_c + (size_t)p * 6));
+  const float pv = box_vol(pb);
+  float best = 0.f;
+  int bi = 0;
+  for (int o = o0; o < o1; ++o) {
+    const Box g = load_box(gt_boxes + (size_t)o * 6);
+    const float v = box_iou(g, box_vol(g), pb, pv);
+    if (o == o0 || v > best) {
+      best = v;
+      bi = o - o0;
+    }
+  }
+  overlap[(size_t)n * P + p] = best;
+  obj[(size_t)n * P + p] = bi;
+}
+
+// best prior per object: first maximum over priors (ssd3d.py:812).  One workgroup per object.
+__global__ __launch_bounds__(256) void match_object_best_kernel(const float* __restrict__ gt_boxes,
+                                                                const float* __restrict__ priors_c,
+                                                                int* __restrict__ prior_for_obj, int P) {
+  __shared__ float sv[256];
+  __shared__ int si[256];
+  const int o = blockIdx.x;
+  const Box g = load_box(gt_boxes + (size_t)o * 6);
+  const float gv = box_vol(g);
+  float best = 0.f;
+  int bi = -1;
+  for (int p = threadIdx.x; p < P; p += 256) {
+    const Box pb = c_to_xyz(load_box(priors_c + (size_t)p * 6));
+    const float v = box_iou(g, gv, pb, box_vol(pb));
+    if (bi < 0 || v > best) {  // ascending p within a thread: strict > keeps the first
+      best = v;
+      bi = p;
+    }
+  }
+  sv[threadIdx.x] = best;
+  si[threadIdx.x] = bi;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) {
+      const float v2 = sv[threadIdx.x + s];
+      const int i2 = si[threadIdx.x + s];
+      const float v1 = sv[threadIdx.x];
+      const int i1 = si[threadIdx.x];
+      const bool take = i2 >= 0 && (i1 < 0 || v2 > v1 || (v2 == v1 && i2 < i1));
+      if (take) {
+        sv[threadIdx.x] = v2;
+        si[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) prior_for_obj[o] = si[0];
+}
+
+// force-match (ssd3d.py:865, :868): every object claims its best prior; duplicates -> highest object wins
+__global__ __launch_bounds__(256) void match_force_kernel(const int* __restrict__ obj_off,
+                                                          const int* __restrict__ prior_for_obj,
+                                                          float* __restrict__ overlap, int* __restrict__ obj, int P) {
+  const int n = blockIdx.x;
+  const int o0 = obj_off[n], o1 = obj_off[n + 1];
+  for (int o = o0 + threadIdx.x; o < o1; o += 256) {
+    const int pf = prior_for_obj[o];
+    bool winner = true;
+    for (int o2 = o + 1; o2 < o1; ++o2) winner = winner && (prior_for_obj[o2] != pf);
+    overlap[(size_t)n * P + pf] = 1.0f;
+    if (winner) obj[(size_t)n * P + pf] = o - o0;
+  }
+}
+
+// labels + threshold band + target encoding (ssd3d.py:871-887)
+__global__ __launch_bounds__(256) void match_encode_kernel(const float* __restrict__ gt_boxes,
+                                                           const long long* __restrict__ gt_labels,
+                                                           const int* __restrict__ obj_off,
+                                                           const float* __restrict__ priors_c,
+                                                           const float* __restrict__ overlap,
+                                                           const int* __restrict__ obj, float thr_lo, float thr_hi,
+                                                           int soft, long long* __restrict__ true_classes,
+                                                           float* __restrict__ true_locs,
+                                                           long long* __restrict__ matched, int P) {
+  const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const size_t idx = (size_t)n * P + p;
+  const int o0 = obj_off[n], o1 = obj_off[n + 1];
+  if (o1 == o0) {  // ssd3d.py:854-855
+    true_classes[idx] = 0;
+    if (matched) matched[idx] = 0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) true_locs[idx * 6 + q] = 0.f;
+    return;
+  }
+  const int o = obj[idx];
+  const float ov = overlap[idx];
+  long long lab = gt_labels[o0 + o];
+  if (ov < thr_lo) lab = 0;
+  else if (soft && ov < thr_hi) lab = -1;
+  true_classes[idx] = lab;
+  if (matched) matched[idx] = o;
+  const Box t = encode_box(xyz_to_c(load_box(gt_boxes + (size_t)(o0 + o) * 6)), load_box(priors_c + (size_t)p * 6));
+#pragma unroll
+  for (int q = 0; q < 6; ++q) true_locs[idx * 6 + q] = t.v[q];
+}
+
+// ---- loss ---------------------------------------------------------------------------------------
+constexpr int MAXC = 16;
+
+__global__ __launch_bounds__(256) void multibox_loss_partial_kernel(const float* __restrict__ locs,
+                                                                    const float* __restrict__ scores,
+                                                                    const long long* __restrict__ true_classes,
+                                                                    const float* __restrict__ true_locs,
+                                                                    double* __restrict__ partials, int total, int ncls) {
+  __shared__ double scratch[8];
+  double ce = 0.0, l1 = 0.0, np = 0.0;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const long long tc = true_classes[i];
+    if (tc >= 0) {
+      const float* x = scores + (size_t)i * ncls;
+      float m = x[0];
+      for (int c = 1; c < ncls; ++c) m = fmaxf(m, x[c]);
+      float se = 0.f;
+      for (int c = 0; c < ncls; ++c) se += expf(x[c] - m);
+      ce += (double)((m + logf(se)) - x[tc]);
+    }
+    if (tc > 0) {
+      np += 1.0;
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) a += fabsf(locs[(size_t)i * 6 + q] - true_locs[(size_t)i * 6 + q]);
+      l1 += (double)a;
+    }
+  }
+  const double t0 = msl::block_sum(ce, scratch);
+  __syncthreads();
+  const double t1 = msl::block_sum(l1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum(np, scratch);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 3 + 0] = t0;
+    partials[blockIdx.x * 3 + 1] = t1;
+    partials[blockIdx.x * 3 + 2] = t2;
+  }
+}
+
+// out[0] = conf_loss, out[1] = loc_loss, out[2] = number of positives (as float)
+__global__ void multibox_loss_finalize_kernel(const double* __restrict__ partials, int nblocks, float* __restrict__ out) {
+  if (threadIdx.x != 0) return;
+  double ce = 0.0, l1 = 0.0, np = 0.0;
+  for (int i = 0; i < nblocks; ++i) {
+    ce += partials[i * 3 + 0];
+    l1 += partials[i * 3 + 1];
+    np += partials[i * 3 + 2];
+  }
+  const float npf = (float)np;
+  out[0] = (float)ce / npf;                 // ssd3d.py:933
+  out[1] = (float)l1 / (npf * 6.0f);         // nn.L1Loss mean over positives x 6 (ssd3d.py:896); 0/0 -> NaN
+  out[2] = npf;
+}
+
+__global__ __launch_bounds__(256) void multibox_loss_bwd_kernel(const float* __restrict__ locs,
+                                                                const float* __restrict__ scores,
+                                                                const long long* __restrict__ true_classes,
+                                                                const float* __restrict__ true_locs,
+                                                                const float* __restrict__ loss_out,
+                                                                const float* __restrict__ upstream,
+                                                                float* __restrict__ dlocs, float* __restrict__ dscores,
+                                                                int total, int ncls) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float npf = loss_out[2];
+  const float gc = upstream[0] / npf, gl = upstream[1] / (npf * 6.0f);
+  const long long tc = true_classes[i];
+  const float* x = scores + (size_t)i * ncls;
+  float* ds = dscores + (size_t)i * ncls;
+  if (tc >= 0) {
+    float m = x[0];
+    for (int c = 1; c < ncls; ++c) m = fmaxf(m, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < ncls; ++c) se += expf(x[c] - m);
+    for (int c = 0; c < ncls; ++c) {
+      const float sm = expf(x[c] - m) / se;
+      ds[c] = gc * (sm - (c == (int)tc ? 1.0f : 0.0f));
+    }
+  } else {
+    for (int c = 0; c < ncls; ++c) ds[c] = 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    float g = 0.f;
+    if (tc > 0) {
+      const float d = locs[(size_t)i * 6 + q] - true_locs[(size_t)i * 6 + q];
+      g = d > 0.f ? gl : (d < 0.f ? -gl : 0.f);
+    }
+    dlocs[(size_t)i * 6 + q] = g;
+  }
+}
+
+constexpr int LOSS_BLOCKS = 64;
+
+}  // namespace
+
+extern "C" {
+
+int msl_make_priors(float* out, int row_off, int D0, int D1, int D2, double scale, int boxes_per_location,
+                    void* stream) {
+  if (D0 <= 0 || D1 <= 0 || D2 <= 0 || boxes_per_location < 1) return MSL_ERR_ARG;
+  const int total = D0 * D1 * D2 * boxes_per_location;
+  hipLaunchKernelGGL(make_priors_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out,
+                     row_off, D0, D1, D2, scale, boxes_per_location);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// op: 0 cxcycz_to_xyz, 1 xyz_to_cxcycz, 2 cxcycz_to_gcxgcygcz (encode), 3 gcxgcygcz_to_cxcycz (decode)
+int msl_box_transform(const float* boxes, const float* priors, float* out, int n, int op, void* stream) {
+  if (n < 0 || op < 0 || op > 3) return MSL_ERR_ARG;
+  if (n == 0) return MSL_OK;
+  hipLaunchKernelGGL(box_transform_kernel, dim3(msl::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, boxes, priors,
+                     out, n, op);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_iou_matrix(const float* set1, const float* set2, float* out, int n1, int n2, int intersection_only,
+                   void* stream) {
+  if (n1 < 0 || n2 < 0) return MSL_ERR_ARG;
+  if (n1 == 0 || n2 == 0) return MSL_OK;
+  hipLaunchKernelGGL(iou_matrix_kernel, dim3(msl::cdiv(n2, 256), n1), dim3(256), 0, (hipStream_t)stream, set1, set2,
+                     out, n1, n2, intersection_only);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// gt_boxes (T,6) corner form, gt_labels (T,), obj_off (N+1,) prefix offsets into them, all on device.
+// scratch: overlap (N,P) f32, obj (N,P) i32, prior_for_obj (T,) i32.  soft != 0 -> two-threshold band.
+int msl_multibox_match(const float* gt_boxes, const long long* gt_labels, const int* obj_off, int total_objects,
+                       const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
+                       int* obj, int* prior_for_obj, long long* true_classes, float* true_locs,
+                       long long* matched, void* stream) {
+  if (N <= 0 || P <= 0 || total_objects < 0) return MSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 gp(msl::cdiv(P, 256), N);
+  if (total_objects > 0) {
+    hipLaunchKernelGGL(match_prior_best_kernel, gp, dim3(256), 0, st, gt_boxes, obj_off, priors_c, overlap, obj, P);
+    MSL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(match_object_best_kernel, dim3(total_objects), dim3(256), 0, st, gt_boxes, priors_c,
+                       prior_for_obj, P);
+    MSL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(match_force_kernel, dim3(N), dim3(256), 0, st, obj_off, prior_for_obj, overlap, obj, P);
+    MSL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(match_encode_kernel, gp, dim3(256), 0, st, gt_boxes, gt_labels, obj_off, priors_c, overlap, obj,
+                     thr_lo, thr_hi, soft, true_classes, true_locs, matched, P);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+size_t msl_multibox_loss_workspace_bytes(void) { return (size_t)LOSS_BLOCKS * 3 * sizeof(double); }
+
+// loss_out[0] = conf, [1] = loc, [2] = number of positive priors
+int msl_multibox_loss_fwd(const float* locs, const float* scores, const long long* true_classes,
+                          const float* true_locs, double* workspace, float* loss_out, int N, int P, int ncls,
+                          void* stream) {
+  if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
+                     true_locs, workspace, N * P, ncls);
+  MSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(multibox_loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, LOSS_BLOCKS, loss_out);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// upstream[0] = dL/dconf, upstream[1] = dL/dloc (device)
+int msl_multibox_loss_bwd(const float* locs, const float* scores, const long long* true_classes,
+                          const float* true_locs, const float* loss_out, const float* upstream, float* dlocs,
+                          float* dscores, int N, int P, int ncls, void* stream) {
+  if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(multibox_loss_bwd_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream, locs,
+                     scores, true_classes, true_locs, loss_out, upstream, dlocs, dscores, N * P, ncls);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+}  // extern "C"

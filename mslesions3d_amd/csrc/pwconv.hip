@@ -1,0 +1,325 @@
+// Pointwise Conv3d(Cin -> Cout, k1, no bias) = per-image GEMM  Y_n[Cout x S] = W[Cout x Cin] . A_n[Cin x S]
+// Reference: Block.conv2 (lesions3d/mobilenet.py:40,45).  NCDHW fp32: the spatial axis S = D*H*W is the
+// contiguous one, so it is the GEMM's N (lane) dimension: every global access is a coalesced row segment.
+//
+// The only GEMM-shaped work on the path -> the only MFMA user (v_mfma_f32_32x32x2_f32: exact fp32, bit
+// equal to a k-ordered fmaf chain).  A_n = relu(bn(z)) is re-created from the raw depthwise output while
+// the tile is staged into LDS; per-channel (sum, sumsq) of the raw output are reduced from the accumulator
+// registers and emitted as fp64 partials for the following BatchNorm.
+//   forward : M = Cout, K = Cin,  W element (m,k) = W[m*K + k]
+//   bwd-data: M = Cin,  K = Cout, W element (m,k) = W[k*M + m]   (transposed read of the same weights)
+//   bwd-wgt : dW[Cout x Cin] = sum_{n,s} dY[co,s] * A[ci,s]      (split over s, fixed-order slab reduction)
+#include "common.hpp"
+#include <algorithm>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 64, BN = 128, BK = 32;
+constexpr int WS_LD = BK + 1;
+
+template <bool AFFINE, bool STATS, bool TRANS_W>
+__global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ X,
+                                                      const float* __restrict__ in_scale,
+                                                      const float* __restrict__ in_shift,
+                                                      const float* __restrict__ Wt, float* __restrict__ Y,
+                                                      double* __restrict__ partials, int M, int K, int S) {
+  __shared__ __align__(16) float Xs[BK][BN];
+  __shared__ float Ws[BM][WS_LD];
+  __shared__ float red[2][2][BM];  // [sum|sumsq][wave column][row]
+  const int n = blockIdx.z, m0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv >> 1, wn = wv & 1;  // 2 x 2 waves: 32 rows x 64 columns each
+  const float* Xn = X + (size_t)n * K * S;
+  const bool vec_ok = (S & 3) == 0;
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    // ---- stage activations: 32 rows x 128 columns
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = (tid >> 5) + i * 8, c4 = (tid & 31) * 4;
+      const int col = s0 + c4;
+      const float* src = Xn + (size_t)(k0 + r) * S + col;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_ok && col + 3 < S) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        if (col < S) v.x = src[0];
+        if (col + 1 < S) v.y = src[1];
+        if (col + 2 < S) v.z = src[2];
+        if (col + 3 < S) v.w = src[3];
+      }
+      if (AFFINE) {
+        const float sc = in_scale[k0 + r], sh = in_shift[k0 + r];
+        v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
+        v.y = col + 1 < S ? msl::act(v.y, sc, sh) : 0.f;
+        v.z = col + 2 < S ? msl::act(v.z, sc, sh) : 0.f;
+        v.w = col + 3 < S ? msl::act(v.w, sc, sh) : 0.f;
+      }
+      *reinterpret_cast<float4*>(&Xs[r][c4]) = v;
+    }
+    // ---- stage weights: 64 x 32
+    if (!TRANS_W) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int m = (tid >> 3) + i * 32, k4 = (tid & 7) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + m < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(m0 + m) * K + k0 + k4);
+        Ws[m][k4] = v.x; Ws[m][k4 + 1] = v.y; Ws[m][k4 + 2] = v.z; Ws[m][k4 + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int k = (tid >> 4) + i * 16, m4 = (tid & 15) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (m0 + m4 + 3 < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + k) * M + m0 + m4);
+        Ws[m4][k] = v.x; Ws[m4 + 1][k] = v.y; Ws[m4 + 2][k] = v.z; Ws[m4 + 3][k] = v.w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int kr = 2 * kk + (lane >> 5);
+      const float a = Ws[wm * 32 + (lane & 31)][kr];
+      const float b0 = Xs[kr][wn * 64 + (lane & 31)];
+      const float b1 = Xs[kr][wn * 64 + 32 + (lane & 31)];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: D[row][col]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* Yn = Y + (size_t)n * M * S;
+  const int colbase = s0 + wn * 64 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    if (row < M && colbase < S) Yn[(size_t)row * S + colbase] = acc0[r];
+    if (row < M && colbase + 32 < S) Yn[(size_t)row * S + colbase + 32] = acc1[r];
+  }
+  if (STATS) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float s = acc0[r] + acc1[r];
+      float q = fmaf(acc0[r], acc0[r], acc1[r] * acc1[r]);
+#pragma unroll
+      for (int m = 16; m > 0; m >>= 1) {
+        s += __shfl_xor(s, m, 64);
+        q += __shfl_xor(q, m, 64);
+      }
+      if ((lane & 31) == 0) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        red[0][wn][row] = s;
+        red[1][wn][row] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BM && m0 + tid < M && partials) {
+      const int NP = gridDim.z * gridDim.x, p = n * gridDim.x + blockIdx.x;
+      partials[(size_t)(m0 + tid) * NP + p] = (double)red[0][0][tid] + (double)red[0][1][tid];
+      partials[((size_t)M + m0 + tid) * NP + p] = (double)red[1][0][tid] + (double)red[1][1][tid];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// bwd-weight.  Block = (k-split, output tile 64 x BNN).  The 4 waves split every 64-position chunk four
+// ways and each keeps the whole tile's accumulators; fixed-order in-block reduction, then one slab per block.
+constexpr int PC = 64, PC_LD = PC + 1;
+
+template <int BNN, bool AFFINE>
+__global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restrict__ dY,
+                                                            const float* __restrict__ Z,
+                                                            const float* __restrict__ in_scale,
+                                                            const float* __restrict__ in_shift,
+                                                            float* __restrict__ slabs, int Cout, int Cin,
+                                                            int S, int N, int chunks_per_img,
+                                                            int chunks_per_block) {
+  constexpr int NSUB_N = BNN / 32;
+  constexpr int NSUB = 2 * NSUB_N;
+  __shared__ __align__(16) float lds[(64 + BNN) * PC_LD > 64 * BNN ? (64 + BNN) * PC_LD : 64 * BNN];
+  float* dys = lds;                 // [64][PC_LD]
+  float* as_ = lds + 64 * PC_LD;    // [BNN][PC_LD]
+  const int ks = blockIdx.x;
+  const int tiles_n = Cin / BNN;
+  const int tm = blockIdx.y / tiles_n, tn = blockIdx.y % tiles_n;
+  const int m0 = tm * 64, n0 = tn * BNN;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int total_chunks = N * chunks_per_img;
+  const int ch_lo = ks * chunks_per_block, ch_hi = min(total_chunks, ch_lo + chunks_per_block);
+  const bool vec_ok = (S & 3) == 0;
+
+  f32x16 acc[NSUB];
+#pragma unroll
+  for (int i = 0; i < NSUB; ++i) acc[i] = (f32x16){0};
+
+  for (int ch = ch_lo; ch < ch_hi; ++ch) {
+    const int n = ch / chunks_per_img, s0 = (ch % chunks_per_img) * PC;
+    const float* dyn = dY + ((size_t)n * Cout + m0) * S;
+    const float* zn = Z + ((size_t)n * Cin + n0) * S;
+#pragma unroll
+    for (int i = 0; i < (64 + BNN) / 16; ++i) {
+      const int r = (tid >> 4) + i * 16, c4 = (tid & 15) * 4, col = s0 + c4;
+      const bool isdy = r < 64;
+      const float* src = isdy ? dyn + (size_t)r * S + col : zn + (size_t)(r - 64) * S + col;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_ok && col + 3 < S) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        if (col < S) v.x = src[0];
+        if (col + 1 < S) v.y = src[1];
+        if (col + 2 < S) v.z = src[2];
+        if (col + 3 < S) v.w = src[3];
+      }
+      if (AFFINE && !isdy) {
+        const float sc = in_scale[n0 + r - 64], sh = in_shift[n0 + r - 64];
+        v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
+        v.y = col + 1 < S ? msl::act(v.y, sc, sh) : 0.f;
+        v.z = col + 2 < S ? msl::act(v.z, sc, sh) : 0.f;
+        v.w = col + 3 < S ? msl::act(v.w, sc, sh) : 0.f;
+      }
+      float* dst = lds + r * PC_LD + c4;
+      dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int pos = wv * 16 + 2 * kk + (lane >> 5);
+      float a[2], b[NSUB_N];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = dys[(i * 32 + (lane & 31)) * PC_LD + pos];
+#pragma unroll
+      for (int j = 0; j < NSUB_N; ++j) b[j] = as_[(j * 32 + (lane & 31)) * PC_LD + pos];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB_N; ++j)
+          acc[i * NSUB_N + j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i * NSUB_N + j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  // in-block reduction over the 4 waves, order 3,2,1,0 (fixed)
+  float* redt = lds;  // [64][BNN]
+  for (int w = 3; w >= 1; --w) {
+    if (wv == w) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NSUB_N; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            const int col = j * 32 + (lane & 31);
+            const float v = acc[i * NSUB_N + j][r];
+            if (w == 3) redt[row * BNN + col] = v;
+            else redt[row * BNN + col] += v;
+          }
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {
+    float* out = slabs + (size_t)ks * Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NSUB_N; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const int col = j * 32 + (lane & 31);
+          out[(size_t)(m0 + row) * Cin + n0 + col] = acc[i * NSUB_N + j][r] + redt[row * BNN + col];
+        }
+  }
+}
+
+// out[i] = sum_k slabs[k][i], k ascending (fixed order)
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                          int count, int nslabs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k) s += slabs[(size_t)k * count + i];
+  out[i] = s;
+}
+
+struct BwPlan {
+  int bnn, ksplit, chunks_per_img, chunks_per_block;
+};
+
+BwPlan bw_plan(int N, int Cin, int Cout, int S) {
+  BwPlan p;
+  p.bnn = (Cin % 64 == 0) ? 64 : 32;
+  p.chunks_per_img = msl::cdiv(S, PC);
+  const int total = N * p.chunks_per_img;
+  const int tiles = (Cout / 64) * (Cin / p.bnn);
+  int ks = std::max(1, std::min(total, 1024 / std::max(1, tiles)));
+  p.chunks_per_block = msl::cdiv(total, ks);
+  p.ksplit = msl::cdiv(total, p.chunks_per_block);
+  return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+int msl_pwconv_fwd_num_partials(int N, int S) { return N * msl::cdiv(S, BN); }
+
+// z (N,Cin,S) raw + input affine -> y (N,Cout,S) raw + stat partials [2][Cout][NP]
+int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
+                   double* partials, int N, int Cin, int Cout, int S, void* stream) {
+  if (N <= 0 || S <= 0 || Cin % BK != 0 || Cout % 4 != 0) return MSL_ERR_ARG;
+  dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cout, BM), N);
+  hipStream_t st = (hipStream_t)stream;
+  if (in_scale) {
+    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<true, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+    else hipLaunchKernelGGL((pw_gemm_kernel<true, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+  } else {
+    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<false, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+    else hipLaunchKernelGGL((pw_gemm_kernel<false, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+  }
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// dy (N,Cout,S) -> g_in (N,Cin,S) = W^T . dy
+int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,
+                        void* stream) {
+  if (N <= 0 || S <= 0 || Cout % BK != 0 || Cin % 4 != 0) return MSL_ERR_ARG;
+  dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cin, BM), N);
+  hipLaunchKernelGGL((pw_gemm_kernel<false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
+                     nullptr, w, g_in, nullptr, Cin, Cout, S);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+size_t msl_pwconv_bwd_weight_workspace_bytes(int N, int Cin, int Cout, int S) {
+  BwPlan p = bw_plan(N, Cin, Cout, S);
+  return (size_t)p.ksplit * Cout * Cin * sizeof(float);
+}
+
+// dW (Cout,Cin) = sum_{n,s} dy[n,co,s] * relu(bn(z))[n,ci,s]
+int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale, const float* in_shift,
+                          float* dw, float* workspace, int N, int Cin, int Cout, int S, void* stream) {
+  if (N <= 0 || S <= 0 || Cin % 32 != 0 || Cout % 64 != 0) return MSL_ERR_ARG;
+  BwPlan p = bw_plan(N, Cin, Cout, S);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(p.ksplit, (Cout / 64) * (Cin / p.bnn));
+  if (p.bnn == 64) {
+    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<64, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    else hipLaunchKernelGGL((pw_bwd_weight_kernel<64, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+  } else {
+    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<32, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    else hipLaunchKernelGGL((pw_bwd_weight_kernel<32, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+  }
+  MSL_LAUNCH_CHECK();
+  const int count = Cout * Cin;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(msl::cdiv(count, 256)), dim3(256), 0, st, workspace, dw, count, p.ksplit);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+}  // extern "C"

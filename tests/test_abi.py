@@ -1,0 +1,71 @@
+"""The C-ABI library loads and exports every symbol include/mslesions3d_hip.h declares, and the ctypes
+signatures used by the Python host agree with the header, parameter by parameter.  No compute (CPU only)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from mslesions3d_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "mslesions3d_hip.h")
+
+
+def _prototypes():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(int|size_t)\s+(msl_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        ret, name, params = m.group(1), m.group(2), " ".join(m.group(3).split())
+        plist = [] if params in ("void", "") else [p.strip() for p in params.split(",")]
+        protos[name] = (ret, plist)
+    return protos
+
+
+def _ctype_of(param):
+    if "*" in param:
+        return ctypes.c_void_p
+    base = param.rsplit(" ", 1)[0].replace("const ", "").strip()
+    return {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
+            "long long": ctypes.c_longlong}[base]
+
+
+def test_header_declares_something():
+    assert len(_prototypes()) >= 40
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    for name in _prototypes():
+        assert hasattr(lib, name), f"{name} declared in the header but not exported by {_lib.LIB_PATH}"
+
+
+def test_python_binding_matches_header():
+    protos = _prototypes()
+    assert sorted(protos) == _lib.exported_names()
+    for name, (ret, plist) in protos.items():
+        res, args = _lib._SIGNATURES[name]
+        assert res is (ctypes.c_int if ret == "int" else ctypes.c_size_t), name
+        assert len(args) == len(plist), f"{name}: header has {len(plist)} parameters, binding {len(args)}"
+        for i, (p, a) in enumerate(zip(plist, args)):
+            assert _ctype_of(p) is a, f"{name} parameter {i} ({p!r}) bound as {a}"
+
+
+def test_pure_host_entry_points():
+    lib = _lib.load()
+    assert lib.msl_abi_version() == 1
+    # shape planning helpers are host-only arithmetic: config A (128^3, batch 4) of BASELINE.json
+    assert lib.msl_stem_conv_fwd_num_partials(4, 64, 64, 64) == 4 * 1024
+    assert lib.msl_dwconv_fwd_variant(4, 32, 64, 64, 64, 2) == 1   # L1: streamed planes
+    assert lib.msl_dwconv_fwd_variant(4, 64, 32, 32, 32, 2) == 2   # L2: LDS-resident slab
+    assert lib.msl_dwconv_fwd_variant(2, 512, 2, 2, 2, 1) == 0     # 64^3 config tail: generic kernel
+    assert lib.msl_pwconv_fwd_num_partials(4, 32768) == 4 * 256
+    assert lib.msl_head_packed_weight_elems(128, 2) == 128 // 4 * 27 * 64
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmsl3d_hip.so")
+    with pytest.raises(_lib.HipKernelError, match="no CPU fallback"):
+        _lib.load()
