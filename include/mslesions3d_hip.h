@@ -129,9 +129,9 @@ int msl_detect_objects(const float* locs, const float* scores, const float* prio
 
 /* ---- optimiser + NaN guard : ssd3d.py:704-722, :258-261 ---------------------------------------------------- */
 /* hp (device, 8 floats): step_size(bias), step_size(other), sqrt(bias_correction2), beta1, beta2, eps,
- * weight_decay, gradient scale.  params laid out [n_bias bias elements | the rest]. */
-int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp, int n,
-                  int n_bias, void* stream);
+ * weight_decay, gradient scale.  is_bias (n bytes): 1 for elements of '.bias' parameters (2*lr group). */
+int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp,
+                  const unsigned char* is_bias, int n, void* stream);
 int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream);
 
 #ifdef __cplusplus

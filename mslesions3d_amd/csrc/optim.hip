@@ -2,8 +2,9 @@
 // Reference: LSSD3D.configure_optimizers (lesions3d/ssd3d.py:704-722): torch.optim.Adam(weight_decay=5e-4)
 // (L2 added to the gradient, not AdamW), bias parameters at 2*lr; NaN guards of ssd3d.py:258-261,:479.
 //
-// All trainable parameters live in ONE contiguous fp32 buffer laid out [biases | everything else], with
-// matching flat grad / exp_avg / exp_avg_sq buffers, so the optimiser is a single HBM-streaming launch
+// All trainable parameters live in ONE contiguous fp32 buffer ordered by backward completion (heads first,
+// stem last) with a byte mask marking the 2*lr (bias) elements, and matching flat grad / exp_avg /
+// exp_avg_sq buffers, so the optimiser is a single HBM-streaming launch
 // (7 x 3.8 MB) and the data-parallel all-reduce works on contiguous buckets.  Hyper-parameters are read
 // from a small device buffer so the launch can sit inside a captured HIP graph.
 #include "common.hpp"
@@ -14,7 +15,7 @@ namespace {
 //     [3] beta1, [4] beta2, [5] eps, [6] weight_decay, [7] gradient scale (1/world_size for DP mean)
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v,
-                                                   const float* __restrict__ hp, int n, int n_bias) {
+                                                   const float* __restrict__ hp, const unsigned char* __restrict__ is_bias, int n) {
   const float ss_b = hp[0], ss_o = hp[1], bc2s = hp[2], b1 = hp[3], b2 = hp[4], eps = hp[5], wd = hp[6], gs = hp[7];
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float pi = p[i];
@@ -23,7 +24,7 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     const float mi = m[i] + (gi - m[i]) * (1.0f - b1);  // exp_avg.lerp_(grad, 1 - beta1)
     const float vi = v[i] * b2 + (1.0f - b2) * gi * gi;  // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
     const float denom = sqrtf(vi) / bc2s + eps;
-    p[i] = pi - (i < n_bias ? ss_b : ss_o) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
+    p[i] = pi - (is_bias[i] ? ss_b : ss_o) * (mi / denom);  // param.addcdiv_(exp_avg, denom, -step_size)
     m[i] = mi;
     v[i] = vi;
   }
@@ -40,11 +41,11 @@ __global__ __launch_bounds__(256) void nan_flag_kernel(const float* __restrict__
 
 extern "C" {
 
-int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp, int n,
-                  int n_bias, void* stream) {
-  if (n <= 0 || n_bias < 0 || n_bias > n) return MSL_ERR_ARG;
+int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp,
+                  const unsigned char* is_bias, int n, void* stream) {
+  if (n <= 0) return MSL_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(min(msl::cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, params,
-                     grads, exp_avg, exp_avg_sq, hp, n, n_bias);
+                     grads, exp_avg, exp_avg_sq, hp, is_bias, n);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

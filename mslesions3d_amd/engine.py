@@ -1,0 +1,369 @@
+"""Static executor for the 3D-SSD network on one MI355X.
+
+The network of ``lesions3d/ssd3d.py:248-263`` (MobileNet-3D backbone ``ssd3d.py:47-100`` /
+``mobilenet.py:26-49`` + prediction heads ``ssd3d.py:113-169``) is a fixed chain, so instead of a tracing
+compiler the executor lays the whole step out once per input shape ("plan"): every activation, gradient,
+BatchNorm vector and workspace is a resident HBM buffer (the 128^3 x 4 plan is ~0.8 GB of 288 GB), and
+forward / backward are fixed sequences of C-ABI kernel launches on the current HIP stream (capturable into a
+HIP graph: no host synchronisation, no allocation inside).
+
+Data convention: conv kernels write RAW outputs + fp64 statistic partials; ``msl_bn_finalize`` turns them into
+a per-channel (scale, shift); the next kernel applies relu(x*scale+shift) while loading.  Only the three
+feature maps the heads read are materialised (in a zero-haloed layout).
+"""
+import torch
+
+from . import _lib
+from ._lib import ptr
+
+BN_ROWS = 6  # scale, shift, mean, invstd, c1, c2
+
+
+def conv_out(d, s):
+    return (d - 1) // s + 1
+
+
+class ParamArena:
+    """All parameters of the model in one flat fp32 HBM buffer, ordered by backward completion (heads first,
+    stem last, gradient-less parameters at the end), with flat grad / Adam-moment twins.  ``nn.Parameter``s
+    become views of the arena, so ``state_dict`` / ``load_state_dict`` keep working with the reference's keys."""
+
+    def __init__(self, model, device):
+        named = list(model.named_parameters())
+        self.no_grad_names = {"rescale_factors"}  # unused in forward (ssd3d.py:251-254): grad stays None
+
+        def order_key(item):
+            name = item[0]
+            if name in self.no_grad_names:
+                return (2, 0, name)
+            if name.startswith("pred_convs"):
+                return (0, 0, name)
+            idx = int(name.split(".")[2])  # base.features.<idx>....
+            return (1, -idx, name)
+
+        ordered = sorted(named, key=order_key)
+        self.names = [n for n, _ in ordered]
+        total = sum(p.numel() for _, p in ordered)
+        self.n_trainable = sum(p.numel() for n, p in ordered if n not in self.no_grad_names)
+        self.flat = torch.empty(total, dtype=torch.float32, device=device)
+        self.grad = torch.zeros(self.n_trainable, dtype=torch.float32, device=device)
+        self.is_bias = torch.zeros(self.n_trainable, dtype=torch.uint8, device=device)
+        self.offsets = {}
+        self.views = {}
+        self.grad_views = {}
+        off = 0
+        with torch.no_grad():
+            for name, p in ordered:
+                n = p.numel()
+                view = self.flat[off:off + n].view(p.shape)
+                view.copy_(p.detach().to(device=device, dtype=torch.float32))
+                p.data = view
+                self.offsets[name] = (off, n)
+                self.views[name] = view
+                if name not in self.no_grad_names:
+                    self.grad_views[name] = self.grad[off:off + n].view(p.shape)
+                    if name.endswith(".bias"):  # ssd3d.py:709 (BN betas match the rule too)
+                        self.is_bias[off:off + n] = 1
+                off += n
+        self.params = {name: p for name, p in ordered}
+
+    def owns(self, model):
+        for name, p in model.named_parameters():
+            v = self.views.get(name)
+            if v is None or p.data_ptr() != v.data_ptr():
+                return False
+        return True
+
+    def bucket_ranges(self, n_buckets):
+        """Contiguous [lo, hi) ranges of the flat gradient that complete in this order during backward."""
+        bounds = [0]
+        # split on parameter boundaries closest to equal byte counts
+        target = self.n_trainable / n_buckets
+        acc = 0
+        for name in self.names:
+            if name in self.no_grad_names:
+                continue
+            acc = self.offsets[name][0] + self.offsets[name][1]
+            if acc >= target * len(bounds) and len(bounds) < n_buckets:
+                bounds.append(acc)
+        bounds.append(self.n_trainable)
+        return [(bounds[i], bounds[i + 1]) for i in range(len(bounds) - 1) if bounds[i + 1] > bounds[i]]
+
+
+class Plan:
+    """Buffers + static shape data for one (batch, input size, mode)."""
+
+    def __init__(self, engine, N, in_dims, device, need_grad):
+        L = _lib.load()
+        m = engine.model
+        self.N, self.in_dims, self.need_grad = N, tuple(in_dims), need_grad
+        f32 = dict(dtype=torch.float32, device=device)
+        specs = engine.layer_specs
+        self.dims = []  # output dims per feature index
+        cur = tuple(in_dims)
+        for sp in specs:
+            cur = tuple(conv_out(d, s) for d, s in zip(cur, sp["stride"]))
+            self.dims.append(cur)
+        self.y = []   # raw conv output of feature i (stem conv / block pointwise)
+        self.z = [None]  # raw depthwise output of block i
+        self.bn_y = []   # (6, C) BatchNorm vectors for y[i]
+        self.bn_z = [None]
+        part_elems = 0
+        ncls = m.n_classes
+        for i, sp in enumerate(specs):
+            D, H, W = self.dims[i]
+            S = D * H * W
+            self.y.append(torch.empty((N, sp["cout"], D, H, W), **f32))
+            self.bn_y.append(torch.zeros((BN_ROWS, sp["cout"]), **f32))
+            if i == 0:
+                part_elems = max(part_elems, 2 * sp["cout"] * L.msl_stem_conv_fwd_num_partials(N, D, H, W))
+            else:
+                pd, ph, pw = self.dims[i - 1]
+                self.z.append(torch.empty((N, sp["cin"], D, H, W), **f32))
+                self.bn_z.append(torch.zeros((BN_ROWS, sp["cin"]), **f32))
+                part_elems = max(part_elems,
+                                 2 * sp["cin"] * L.msl_dwconv_fwd_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]),
+                                 2 * sp["cout"] * L.msl_pwconv_fwd_num_partials(N, S))
+                if need_grad:
+                    part_elems = max(part_elems,
+                                     sp["cin"] * 27 * L.msl_dwconv_bwd_weight_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]),
+                                     2 * sp["cin"] * L.msl_bn_relu_bwd_num_partials(N, S))
+            if need_grad:
+                part_elems = max(part_elems, 2 * sp["cout"] * L.msl_bn_relu_bwd_num_partials(N, S))
+        self.partials = torch.empty(max(part_elems, 1), dtype=torch.float64, device=device)
+
+        # heads
+        self.feat_ids = list(m.aspect_ratios.keys())
+        self.prior_off, off = {}, 0
+        for f in self.feat_ids:
+            self.prior_off[f] = off
+            D, H, W = self.dims[f]
+            off += D * H * W * m.boxes_per_location
+        self.P = off
+        self.fpad, self.Wf, self.Wb, self.head_ws = {}, {}, {}, {}
+        for f in self.feat_ids:
+            C = specs[f]["cout"]
+            D, H, W = self.dims[f]
+            self.fpad[f] = torch.zeros((N, C, D + 2, H + 2, W + 2), **f32)
+            ne = L.msl_head_packed_weight_elems(C, ncls)
+            self.Wf[f] = torch.empty(ne, **f32)
+            self.Wb[f] = torch.empty(ne, **f32)
+            ws = max(L.msl_head_fwd_workspace_bytes(N, C, D, H, W, ncls),
+                     L.msl_head_bwd_weight_workspace_bytes(N, C, D, H, W, ncls) if need_grad else 0)
+            self.head_ws[f] = torch.empty(max(ws // 4, 1), **f32)
+        self.locs = torch.empty((N, self.P, 6), **f32)
+        self.scores = torch.empty((N, self.P, ncls), **f32)
+        self.nan_flag = torch.zeros(1, dtype=torch.int32, device=device)
+
+        if need_grad:
+            self.g_y = [torch.empty_like(t) for t in self.y]
+            self.g_z = [None] + [torch.empty_like(t) for t in self.z[1:]]
+            mt16 = 16 * ((12 + 2 * ncls + 15) // 16)
+            self.dO = {f: torch.zeros((N, mt16) + tuple(d + 2 for d in self.dims[f]), **f32) for f in self.feat_ids}
+            ws = L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"])
+            for i in range(1, len(specs)):
+                D, H, W = self.dims[i]
+                ws = max(ws, L.msl_pwconv_bwd_weight_workspace_bytes(N, specs[i]["cin"], specs[i]["cout"], D * H * W))
+            self.ws = torch.empty(max(ws // 4, 1), **f32)
+        self.saved_input = None
+        self.generation = 0
+
+
+class Engine:
+    def __init__(self, model):
+        self.model = model
+        self.arena = None
+        self.plans = {}
+        feats = model.base.features
+        specs = []
+        for i, f in enumerate(feats):
+            if i == 0:
+                conv = f[0]
+                specs.append(dict(kind="stem", cin=conv.in_channels, cout=conv.out_channels, stride=tuple(conv.stride)))
+            else:
+                specs.append(dict(kind="block", cin=f.conv1.in_channels, cout=f.conv2.out_channels,
+                                  stride=tuple(f.conv1.stride)))
+        self.layer_specs = specs
+
+    # ------------------------------------------------------------------------------------------------
+    def ensure_arena(self, device):
+        if self.arena is None or self.arena.flat.device != device or not self.arena.owns(self.model):
+            self.arena = ParamArena(self.model, device)
+            self.plans = {}
+        return self.arena
+
+    def plan_for(self, x, need_grad):
+        key = (x.shape[0], tuple(x.shape[2:]), x.device, need_grad)
+        p = self.plans.get(key)
+        if p is None:
+            p = Plan(self, x.shape[0], x.shape[2:], x.device, need_grad)
+            self.plans[key] = p
+        return p
+
+    @staticmethod
+    def _stream():
+        return torch.cuda.current_stream().cuda_stream
+
+    def _bn_fwd(self, bn, vec, partials, NP, count, training, st):
+        C = vec.shape[1]
+        if training:
+            mom = 0.1 if bn.momentum is None else bn.momentum
+            _lib.call("msl_bn_finalize", ptr(partials), NP, float(count), ptr(bn.weight), ptr(bn.bias),
+                      ptr(bn.running_mean), ptr(bn.running_var), ptr(bn.num_batches_tracked), mom, bn.eps,
+                      ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C, st)
+        else:
+            _lib.call("msl_bn_eval_affine", ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean), ptr(bn.running_var),
+                      bn.eps, ptr(vec[0]), ptr(vec[1]), C, st)
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, x, training, need_grad, want_features=False):
+        """x (N,Cin,D,H,W) fp32 on the GPU -> (locs (N,P,6), scores (N,P,n_classes)) [+ dict of feature maps]."""
+        if not x.is_cuda:
+            raise _lib.HipKernelError("mslesions3d_amd runs on the HIP device only (no CPU fallback): move the "
+                                      "model and the input to 'cuda'")
+        L = _lib.load()
+        m = self.model
+        x = x.contiguous().float()
+        self.ensure_arena(x.device)
+        pl = self.plan_for(x, need_grad)
+        pl.generation += 1
+        pl.saved_input = x
+        pl.trained_mode = training
+        st = self._stream()
+        N = pl.N
+        feats = m.base.features
+        specs = self.layer_specs
+        part = pl.partials
+        pp = ptr(part) if training else None
+        pl.nan_flag.zero_()
+
+        # stem (features[0] = Conv3d + BN + ReLU)
+        D, H, W = pl.in_dims
+        sd, sh, sw = specs[0]["stride"]
+        _lib.call("msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), pp, N, specs[0]["cin"], D, H, W,
+                  sd, sh, sw, st)
+        od, oh, ow = pl.dims[0]
+        self._bn_fwd(feats[0][1], pl.bn_y[0], part, L.msl_stem_conv_fwd_num_partials(N, od, oh, ow),
+                     N * od * oh * ow, training, st)
+        out_feats = {}
+        for i in range(1, len(specs)):
+            sp, blk = specs[i], feats[i]
+            pd, ph, pw = pl.dims[i - 1]
+            D, H, W = pl.dims[i]
+            S = D * H * W
+            s = sp["stride"][0]
+            _lib.call("msl_dwconv_fwd", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
+                      ptr(blk.conv1.weight), ptr(pl.z[i]), pp, N, sp["cin"], pd, ph, pw, s, 0, st)
+            self._bn_fwd(blk.bn1, pl.bn_z[i], part, L.msl_dwconv_fwd_num_partials(N, sp["cin"], pd, ph, pw, s),
+                         N * S, training, st)
+            _lib.call("msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(blk.conv2.weight),
+                      ptr(pl.y[i]), pp, N, sp["cin"], sp["cout"], S, st)
+            self._bn_fwd(blk.bn2, pl.bn_y[i], part, L.msl_pwconv_fwd_num_partials(N, S), N * S, training, st)
+            if i in pl.fpad:
+                plain = None
+                if want_features:
+                    plain = torch.empty((N, sp["cout"], D, H, W), dtype=torch.float32, device=x.device)
+                    out_feats[i] = plain
+                _lib.call("msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]), ptr(pl.bn_y[i][1]), ptr(plain),
+                          ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
+        self._heads_forward(pl, st)
+        _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
+        _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
+        if want_features:
+            return pl.locs, pl.scores, out_feats
+        return pl.locs, pl.scores
+
+    def _heads_forward(self, pl, st):
+        m = self.model
+        ncls = m.n_classes
+        for k, f in enumerate(pl.feat_ids):
+            lc, cc = m.pred_convs.loc_convs[k], m.pred_convs.cl_convs[k]
+            C = self.layer_specs[f]["cout"]
+            D, H, W = pl.dims[f]
+            _lib.call("msl_head_pack_weights", ptr(lc.weight), ptr(cc.weight), ptr(pl.Wf[f]), ptr(pl.Wb[f]), C, ncls, st)
+            _lib.call("msl_head_conv_fwd", ptr(pl.fpad[f]), ptr(pl.Wf[f]), ptr(lc.bias), ptr(cc.bias), ptr(pl.locs),
+                      ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
+
+    # ------------------------------------------------------------------------------------------------
+    def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st):
+        """In place: g (= dL/d relu(bn(y))) becomes dL/dy; writes dgamma/dbeta into the gradient arena."""
+        L = _lib.load()
+        gv = self.arena.grad_views
+        NP = L.msl_bn_relu_bwd_num_partials(N, S)
+        _lib.call("msl_bn_relu_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
+                  ptr(pl.partials), N, C, S, st)
+        _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(count), ptr(gv[bn_name + ".weight"]),
+                  ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
+        _lib.call("msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
+                  ptr(vec[4]), ptr(vec[5]), ptr(g), N, C, S, st)
+
+    def backward(self, pl, dlocs, dscores, on_bucket_ready=None):
+        """Given dL/dlocs, dL/dscores, fill the flat gradient arena.  ``on_bucket_ready(k)`` is called right after
+        the launches that complete gradient bucket k (0 = heads .. last = stem) have been enqueued."""
+        if not pl.need_grad or not pl.trained_mode:
+            raise RuntimeError("backward needs a train-mode forward made with gradients enabled")
+        m = self.model
+        gv = self.arena.grad_views
+        st = self._stream()
+        N, ncls = pl.N, m.n_classes
+        specs = self.layer_specs
+        feats = m.base.features
+        dlocs = dlocs.contiguous()
+        dscores = dscores.contiguous()
+        # heads
+        for k, f in enumerate(pl.feat_ids):
+            C = specs[f]["cout"]
+            D, H, W = pl.dims[f]
+            _lib.call("msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P, pl.prior_off[f],
+                      ncls, st)
+            pre = f"pred_convs.loc_convs.{k}", f"pred_convs.cl_convs.{k}"
+            _lib.call("msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
+                      ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
+                      ptr(pl.head_ws[f]), N, C, D, H, W, ncls, st)
+            _lib.call("msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W, ncls, st)
+        if on_bucket_ready:
+            on_bucket_ready("heads")
+        last = len(specs) - 1
+        for i in range(last, 0, -1):
+            sp = specs[i]
+            D, H, W = pl.dims[i]
+            S = D * H * W
+            pd, ph, pw = pl.dims[i - 1]
+            s = sp["stride"][0]
+            name = f"base.features.{i}"
+            if i not in pl.fpad and i == last:
+                raise RuntimeError("the last backbone feature must feed a head")
+            # y_i = pw(relu(bn1(z_i))): BN2 backward, then the two GEMMs
+            self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st)
+            _lib.call("msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
+                      ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, st)
+            _lib.call("msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
+                      sp["cout"], S, st)
+            # z_i = dw(relu(bn(y_{i-1}))): BN1 backward, then depthwise bwd-weight / bwd-data
+            self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
+            _lib.call("msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
+                      ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials), N, sp["cin"], pd, ph,
+                      pw, s, st)
+            accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
+            _lib.call("msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
+                      sp["cin"], pd, ph, pw, s, accumulate, st)
+            if on_bucket_ready:
+                on_bucket_ready(i)
+        # stem
+        od, oh, ow = pl.dims[0]
+        S0 = od * oh * ow
+        self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st)
+        D, H, W = pl.in_dims
+        sd, sh, sw = specs[0]["stride"]
+        _lib.call("msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]),
+                  ptr(pl.ws), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
+        if on_bucket_ready:
+            on_bucket_ready(0)
+
+    def check_nan(self, pl):
+        """One host sync: raise like ssd3d.py:258-261 if the forward produced NaN."""
+        flag = int(pl.nan_flag.item())
+        if flag & 2:
+            raise Exception("Oh no not this NaN error again... (forward SSD), CLASSES_SCORES is nan!")
+        if flag & 1:
+            raise Exception("Oh no not this NaN error again... (forward SSD), LOCS is nan!")

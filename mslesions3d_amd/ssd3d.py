@@ -1,0 +1,653 @@
+"""3D SSD lesion detector on MI355X — host-side mirror of the reference's ``lesions3d/ssd3d.py``.
+
+Same classes, constructor arguments, attributes, method names, return types, ``state_dict`` keys and error
+behaviour as the reference; the arithmetic runs in the hand-written HIP kernels of
+``mslesions3d_amd/csrc`` through the C ABI of ``include/mslesions3d_hip.h``.  PyTorch is used for device memory,
+streams, autograd bookkeeping and (in ``parallel.py``) RCCL — not for arithmetic.  There is no CPU fallback.
+
+Lightning is not required: ``LSSD3D`` is a plain ``nn.Module`` that keeps the LightningModule surface the
+reference's scripts use (``training_step`` / ``validation_step`` / ``predict_step`` / ``configure_optimizers`` /
+``load_from_checkpoint`` / ``log``), and ``mslesions3d_amd.trainer`` provides the minimal loop.
+"""
+import math
+import warnings
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib
+from ._lib import ptr
+from .base_network import CONVNET_CONFIGS, ConvNetBase  # noqa: F401  (re-exported like the reference)
+from .engine import Engine
+from .mobilenet import MOBILENET_CONFIGS, Block, conv_bn
+from .utils import *  # noqa: F401,F403  (the reference does `from utils import *`, ssd3d.py:14)
+from .utils import calculate_mAP
+
+device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+ASPECT_RATIOS = {3: [1.], 5: [1.], 7: [1]}
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _conv_out(d, s):
+    return (d - 1) // s + 1
+
+
+class MobileNetBase(nn.Module):
+    """ssd3d.py:47-110."""
+
+    def __init__(self, config="mobilenet", in_channels=1, width_mult=1., cube=False, aspect_ratios=None):
+        super(MobileNetBase, self).__init__()
+        if aspect_ratios is None:
+            aspect_ratios = ASPECT_RATIOS
+        self.aspect_ratios = aspect_ratios
+        self.in_channels = in_channels
+        self.config = MOBILENET_CONFIGS[config]
+        input_channel = int(self.config[0] * width_mult)
+        cfg = self.config[1:]
+        first_stride = (1, 2, 2) if not cube else (2, 2, 2)  # ssd3d.py:60
+        features = [conv_bn(in_channels, input_channel, first_stride)]
+        for c, n, s in cfg:  # ssd3d.py:65-75 (truncated after the last feature that feeds a head)
+            if len(features) - 1 == max(self.aspect_ratios.keys()):
+                break
+            output_channel = int(c * width_mult)
+            for i in range(n):
+                if len(features) - 1 == max(aspect_ratios.keys()):
+                    break
+                stride = s if i == 0 else 1
+                features.append(Block(input_channel, output_channel, stride))
+                input_channel = output_channel
+        self.features = nn.Sequential(*features)
+
+    def init(self):
+        """ssd3d.py:80-84 — iterates ``children()`` (an ``nn.Sequential``), never a Conv3d: a no-op in the
+        reference, kept a no-op here."""
+        for c in self.children():
+            if isinstance(c, nn.Conv3d):
+                nn.init.kaiming_uniform_(c.weight)
+                nn.init.constant_(c.bias, 0.)
+
+    def forward(self, image):
+        """Stand-alone backbone pass -> {feature index: activation}.  (Inside LSSD3D the fused executor is used.)"""
+        out = image
+        out_features = {}
+        for i, feat in enumerate(self.features):
+            out = feat(out)
+            if i in self.aspect_ratios:
+                out_features[i] = out
+                if torch.isnan(out).sum() > 0:  # ssd3d.py:95-98
+                    raise Exception("Yesssss this NaN error again in the base network")
+        return out_features
+
+    def feature_map_dims(self, input_size):
+        dims, chans, cur = {}, [], tuple(input_size)
+        for i, layer in enumerate(self.features):
+            if i == 0:
+                stride, c = tuple(layer[0].stride), layer[0].out_channels
+            else:
+                stride, c = tuple(layer.conv1.stride), layer.conv2.out_channels
+            cur = tuple(_conv_out(d, s) for d, s in zip(cur, stride))
+            dims[i] = cur
+            chans.append(c)
+        return dims, chans
+
+    def get_feature_map_infos(self, input_size, device):
+        """ssd3d.py:102-110.  The reference measures the shapes with a train-mode dummy pass of ``torch.randn``;
+        the shapes are computed in closed form here, and the same amount of RNG is drawn so that seeded
+        construction yields the same weights as the reference (the heads are initialised after the first draw).
+        The dummy pass's side effect on the BatchNorm running statistics is reproduced by
+        ``LSSD3D.replay_reference_init_side_effects()`` when a GPU is present."""
+        torch.randn((1, self.in_channels, *input_size))
+        return self.feature_map_dims(input_size)
+
+
+class PredictionConvolutions(nn.Module):
+    """ssd3d.py:113-169."""
+
+    def __init__(self, n_classes, width_mult, aspect_ratios, features_n_channels, boxes_per_location=2):
+        super(PredictionConvolutions, self).__init__()
+        self.n_classes = n_classes
+        n_boxes = {feat: len(aspect_ratios[feat]) + boxes_per_location - 1 for feat in aspect_ratios}
+        if any(v != 2 for v in n_boxes.values()):
+            raise NotImplementedError("the HIP head kernel is built for 2 priors per location "
+                                      "(the reference hard-codes boxes_per_location = 2, ssd3d.py:213)")
+        self.feature_ids = list(aspect_ratios.keys())
+        loc_convs, cl_convs = [], []
+        for f in aspect_ratios:
+            f_n_channels = int(features_n_channels[f] * width_mult)
+            loc_convs.append(nn.Conv3d(f_n_channels, n_boxes[f] * 6, kernel_size=3, padding=1))
+            cl_convs.append(nn.Conv3d(f_n_channels, n_boxes[f] * n_classes, kernel_size=3, padding=1))
+        self.loc_convs = nn.ModuleList(loc_convs)
+        self.cl_convs = nn.ModuleList(cl_convs)
+
+    def init(self):
+        """ssd3d.py:137-141 — a no-op for the same reason as MobileNetBase.init."""
+        for c in self.children():
+            if isinstance(c, nn.Conv3d):
+                nn.init.kaiming_uniform_(c.weight)
+                nn.init.constant_(c.bias, 0.)
+
+    def forward(self, feats):
+        """feats: {feature index: activation (N,C,D,H,W)} -> locs (N,P,6), classes_scores (N,P,n_classes)."""
+        L = _lib.load()
+        keys = list(feats.keys())
+        first = feats[keys[0]]
+        if not first.is_cuda:
+            raise _lib.HipKernelError("PredictionConvolutions runs on the HIP device only (no CPU fallback)")
+        N = first.size(0)
+        P = sum(2 * feats[k].shape[2] * feats[k].shape[3] * feats[k].shape[4] for k in keys)
+        locs = torch.empty((N, P, 6), dtype=torch.float32, device=first.device)
+        scores = torch.empty((N, P, self.n_classes), dtype=torch.float32, device=first.device)
+        off = 0
+        st = _stream()
+        for i, key in enumerate(keys):
+            f = feats[key].float()
+            _, C, D, H, W = f.shape
+            pad = torch.zeros((N, C, D + 2, H + 2, W + 2), dtype=torch.float32, device=f.device)
+            pad[:, :, 1:-1, 1:-1, 1:-1] = f
+            ne = L.msl_head_packed_weight_elems(C, self.n_classes)
+            Wf = torch.empty(ne, dtype=torch.float32, device=f.device)
+            Wb = torch.empty(ne, dtype=torch.float32, device=f.device)
+            ws = torch.empty(max(L.msl_head_fwd_workspace_bytes(N, C, D, H, W, self.n_classes) // 4, 1),
+                             dtype=torch.float32, device=f.device)
+            lc, cc = self.loc_convs[i], self.cl_convs[i]
+            _lib.call("msl_head_pack_weights", ptr(lc.weight), ptr(cc.weight), ptr(Wf), ptr(Wb), C, self.n_classes, st)
+            _lib.call("msl_head_conv_fwd", ptr(pad), ptr(Wf), ptr(lc.bias), ptr(cc.bias), ptr(locs), ptr(scores), ptr(ws),
+                      N, C, D, H, W, P, off, self.n_classes, st)
+            off += 2 * D * H * W
+        return locs, scores
+
+
+class _SSDFunction(torch.autograd.Function):
+    """Whole-network autograd node: forward = Engine.forward, backward = Engine.backward."""
+
+    @staticmethod
+    def forward(ctx, model, need_grad, image, *params):
+        eng = model._engine
+        locs, scores = eng.forward(image, training=model.training, need_grad=need_grad)
+        pl = eng.plan_for(image, need_grad)
+        ctx.model, ctx.plan, ctx.gen, ctx.names = model, pl, pl.generation, model._param_names
+        return locs.clone(), scores.clone()
+
+    @staticmethod
+    def backward(ctx, dlocs, dscores):
+        eng, pl = ctx.model._engine, ctx.plan
+        if pl.generation != ctx.gen:
+            raise RuntimeError("the activations of this forward pass were overwritten by a later forward pass "
+                               "with the same shape; call backward() before running the model again")
+        eng.backward(pl, dlocs, dscores)
+        gv = eng.arena.grad_views
+        return (None, None, None) + tuple(gv[n].clone() if n in gv else None for n in ctx.names)
+
+
+class LSSD3D(nn.Module):
+    """The SSD 3D network (ssd3d.py:172-738): MobileNet-3D base + prediction convolutions + priors + loss."""
+
+    def __init__(self,
+                 n_classes,
+                 input_channels=3,
+                 input_size=(64, 64, 64),
+                 threshold=0.5,  # threshold for box matching in MultiBoxLoss
+                 alpha=1.,
+                 lr=1.3e-5,
+                 base_network_config="mobilenet",
+                 width_mult=1.,
+                 min_score=0.5,
+                 max_overlap=0.5,  # for box matching
+                 min_overlap=0.5,  # for evaluation metrics
+                 top_k=100,
+                 scheduler="CosineAnnealingLR",
+                 use_wandb=False,
+                 batch_size=8,
+                 compute_metric_every_n_epochs=1,
+                 comments="",
+                 aspect_ratios={},
+                 min_object_size=6,
+                 max_object_size=14,
+                 scales={},
+                 boxes_per_location=2
+                 ):
+        super(LSSD3D, self).__init__()
+        if aspect_ratios == {}:
+            aspect_ratios = ASPECT_RATIOS
+        self.hparams = dict(n_classes=n_classes, input_channels=input_channels, input_size=tuple(input_size),
+                            threshold=threshold, alpha=alpha, lr=lr, base_network_config=base_network_config,
+                            width_mult=width_mult, min_score=min_score, max_overlap=max_overlap,
+                            min_overlap=min_overlap, top_k=top_k, scheduler=scheduler, use_wandb=use_wandb,
+                            batch_size=batch_size, compute_metric_every_n_epochs=compute_metric_every_n_epochs,
+                            comments=comments, aspect_ratios=aspect_ratios, min_object_size=min_object_size,
+                            max_object_size=max_object_size, scales=scales, boxes_per_location=boxes_per_location)
+        self.base_network_config = base_network_config
+        self.cube = input_size[0] == input_size[1] == input_size[2]
+        self.input_size = tuple(input_size)
+        self.input_channels = input_channels
+        self.width_mult = width_mult
+        self.aspect_ratios = aspect_ratios
+        self.boxes_per_location = 2  # ssd3d.py:213 (the constructor argument is ignored by the reference)
+        self.n_classes = n_classes
+        self._make_base_and_prediction_layers()
+        self.lr = lr
+        self.min_score = min_score
+        self.max_overlap = max_overlap
+        self.min_overlap = min_overlap
+        self.top_k = top_k
+        self.scheduler = scheduler
+        self.use_wandb = use_wandb
+        self.batch_size = batch_size
+        self.compute_metric_every_n_epochs = compute_metric_every_n_epochs
+        self.comments = comments
+        self.alpha = alpha
+        self.threshold = threshold
+
+        if scales == {}:  # ssd3d.py:228-234
+            self.scales = {layer: scale for layer, scale in zip(self.aspect_ratios.keys(),
+                                                                np.linspace(min_object_size / input_size[0],
+                                                                            max_object_size / input_size[0],
+                                                                            len(self.aspect_ratios)))}
+        else:
+            self.scales = scales
+
+        features_n_channels = self.base.get_feature_map_infos(self.input_size, self.device)[1]  # ssd3d.py:238
+        n_channel_rescale = int(features_n_channels[min(self.aspect_ratios.keys())] * self.width_mult)
+        self.rescale_factors = nn.Parameter(torch.FloatTensor(1, n_channel_rescale, 1, 1, 1))  # unused in forward
+        nn.init.constant_(self.rescale_factors, 20)
+
+        # Lightning-surface state
+        self.current_epoch = 0
+        self.global_step = 0
+        self.logged = {}
+        self._scheduler = None
+        self._engine = Engine(self)
+        self._param_names = [n for n, _ in self.named_parameters()]
+        self._det_ws = {}
+
+        # Prior boxes (ssd3d.py:244).  The draw below keeps RNG parity with the reference's third dummy pass.
+        self.base.get_feature_map_infos(self.input_size, self.device)
+        self.priors_cxcycz = self.create_prior_boxes(_draw=False) if torch.cuda.is_available() else None
+        self.loss_fn = MultiBoxLoss(self.priors_cxcycz, threshold=threshold, alpha=alpha)
+
+    # -- Lightning surface ------------------------------------------------------------------------------
+    @property
+    def device(self):
+        return next(self.parameters()).device
+
+    def log(self, name, value, *args, **kwargs):
+        self.logged[name] = float(value)
+
+    def lr_schedulers(self):
+        return self._scheduler
+
+    def save_hyperparameters(self, *a, **k):
+        pass
+
+    # -- construction ---------------------------------------------------------------------------------------
+    def _make_base_and_prediction_layers(self):
+        if 'mobilenet' in self.base_network_config:
+            if self.width_mult != 1.:
+                raise NotImplementedError("width_mult != 1 crashes in the reference (ssd3d.py:130, SURVEY §0.2-8)")
+            self.base = MobileNetBase(config=self.base_network_config, in_channels=self.input_channels,
+                                      width_mult=self.width_mult, cube=self.cube, aspect_ratios=self.aspect_ratios)
+            features_n_channels = self.base.get_feature_map_infos(self.input_size, None)[1]  # ssd3d.py:270
+            self.pred_convs = PredictionConvolutions(self.n_classes, width_mult=self.width_mult,
+                                                     aspect_ratios=self.aspect_ratios,
+                                                     features_n_channels=features_n_channels,
+                                                     boxes_per_location=self.boxes_per_location)
+        elif 'convnet' in self.base_network_config:
+            raise NotImplementedError("the 'convnet' backbone is unreachable in the reference (ssd3d.py:281) and needs "
+                                      "MONAI's Convolution block; only 'mobilenet' is built")
+        else:
+            raise Exception(
+                f"Unknown base network name. Expected 'mobilenet' or 'convnet' but got {self.base_network_config}")
+
+    def create_prior_boxes(self, per_feature_map=False, _draw=True):
+        """ssd3d.py:286-342 on the GPU: (P,6) centre-size priors, fp64 arithmetic rounded once to fp32, clamped
+        to [0,1]; row order scale-major, then (i,j,k) row-major, then the 2 sizes; centre = ((j+.5)/d1,
+        (i+.5)/d0, (k+.5)/d2) exactly like the reference."""
+        fmd = (self.base.get_feature_map_infos(self.input_size, self.device) if _draw
+               else self.base.feature_map_dims(self.input_size))[0]
+        if not torch.cuda.is_available():
+            raise _lib.HipKernelError("create_prior_boxes needs the HIP device (no CPU fallback)")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        feats = list(self.aspect_ratios.keys())
+        P = sum(fmd[f][0] * fmd[f][1] * fmd[f][2] * self.boxes_per_location for f in feats)
+        out = torch.empty((P, 6), dtype=torch.float32, device=dev)
+        off, ranges = 0, {}
+        for f in feats:
+            d0, d1, d2 = fmd[f]
+            _lib.call("msl_make_priors", ptr(out), off, d0, d1, d2, float(self.scales[f]), self.boxes_per_location,
+                      _stream())
+            ranges[f] = (off, off + d0 * d1 * d2 * self.boxes_per_location)
+            off = ranges[f][1]
+        if not per_feature_map:
+            return out
+        host = out.cpu()
+        return {f: host[lo:hi].tolist() for f, (lo, hi) in ranges.items()}
+
+    def _ensure_device_state(self, dev):
+        if self.priors_cxcycz is None or self.priors_cxcycz.device != dev:
+            with torch.cuda.device(dev):
+                self.priors_cxcycz = self.create_prior_boxes(_draw=False)
+            self.loss_fn.set_priors(self.priors_cxcycz)
+
+    def init(self):
+        print("[INFO] Initializing model weights")
+        self.base.init()
+        self.pred_convs.init()
+
+    def replay_reference_init_side_effects(self):
+        """the reference's constructor pushes three train-mode ``randn`` batches through the
+        backbone, leaving every BatchNorm with num_batches_tracked == 3 and nudged running statistics.  Call
+        this once (after moving the model to the GPU) to reproduce that state with the HIP kernels."""
+        was_training = self.training
+        self.train()
+        with torch.no_grad():
+            for _ in range(3):
+                x = torch.randn((1, self.input_channels, *self.input_size)).to(self.device)
+                self._engine.forward(x, training=True, need_grad=False)
+        self.train(was_training)
+
+    # -- forward ------------------------------------------------------------------------------------------
+    def forward(self, image):
+        """ssd3d.py:248-263: image (N,C,D,H,W) -> locs (N,P,6), classes_scores (N,P,n_classes)."""
+        if not image.is_cuda:
+            raise _lib.HipKernelError("mslesions3d_amd runs on the HIP device only (no CPU fallback): move the model "
+                                      "and the input to 'cuda'")
+        self._ensure_device_state(image.device)
+        self._engine.ensure_arena(image.device)
+        params = [p for _, p in self.named_parameters()]
+        need_grad = self.training and torch.is_grad_enabled()
+        locs, classes_scores = _SSDFunction.apply(self, need_grad, image, *params)
+        self._engine.check_nan(self._engine.plan_for(image, need_grad))
+        return locs, classes_scores
+
+    # -- detection ------------------------------------------------------------------------------------------
+    def _detect_workspace(self, N, P, ncls, top_k, dev):
+        key = (N, P, ncls, top_k, dev)
+        ws = self._det_ws.get(key)
+        if ws is None:
+            cap, k1 = 10 * top_k, ncls - 1
+            wn = (cap + 63) // 64
+            f32, i32, i64 = torch.float32, torch.int32, torch.int64
+            ws = dict(probs=torch.empty((N, k1, P), dtype=f32, device=dev),
+                      boxes=torch.empty((N, P, 6), dtype=f32, device=dev),
+                      sorted_idx=torch.zeros((N, k1, cap), dtype=i32, device=dev),
+                      ncand=torch.zeros(N * k1, dtype=i32, device=dev),
+                      mask=torch.zeros((N, k1, cap, wn), dtype=i64, device=dev),
+                      keep=torch.zeros((N, k1, wn), dtype=i64, device=dev),
+                      nkept=torch.zeros(N * k1, dtype=i32, device=dev),
+                      tmp_s=torch.empty((N, k1 * cap), dtype=f32, device=dev),
+                      tmp_r=torch.empty((N, k1 * cap), dtype=i32, device=dev),
+                      ob=torch.empty((N, top_k, 6), dtype=f32, device=dev),
+                      os=torch.empty((N, top_k), dtype=f32, device=dev),
+                      ol=torch.empty((N, top_k), dtype=i64, device=dev),
+                      op=torch.empty((N, top_k), dtype=i64, device=dev),
+                      oc=torch.zeros(N, dtype=i32, device=dev))
+            self._det_ws[key] = ws
+        return ws
+
+    def detect_objects(self, predicted_locs, predicted_scores, min_score, max_overlap, top_k, return_prior_index=False):
+        """ssd3d.py:344-460.  -> three lists of length N: boxes (k,6) corner-form fractional, labels (k,) int64,
+        scores (k,) fp32.  Equal scores are ordered by ascending prior index (stable sort)."""
+        if not predicted_locs.is_cuda:
+            raise _lib.HipKernelError("detect_objects runs on the HIP device only (no CPU fallback)")
+        self._ensure_device_state(predicted_locs.device)
+        N = predicted_locs.size(0)
+        P = self.priors_cxcycz.size(0)
+        assert P == predicted_locs.size(1) == predicted_scores.size(1)  # ssd3d.py:370
+        ncls = predicted_scores.size(2)
+        locs = predicted_locs.detach().contiguous().float()
+        scores = predicted_scores.detach().contiguous().float()
+        w = self._detect_workspace(N, P, ncls, int(top_k), locs.device)
+        _lib.call("msl_detect_objects", ptr(locs), ptr(scores), ptr(self.priors_cxcycz), N, P, ncls, float(min_score),
+                  float(max_overlap), int(top_k), ptr(w["probs"]), ptr(w["boxes"]), ptr(w["sorted_idx"]), ptr(w["ncand"]),
+                  ptr(w["mask"]), ptr(w["keep"]), ptr(w["nkept"]), ptr(w["tmp_s"]), ptr(w["tmp_r"]), ptr(w["ob"]),
+                  ptr(w["os"]), ptr(w["ol"]), ptr(w["op"]), ptr(w["oc"]), _stream())
+        counts = w["oc"].tolist()  # the only host sync
+        boxes = [w["ob"][i, :counts[i]].clone() for i in range(N)]
+        labels = [w["ol"][i, :counts[i]].clone() for i in range(N)]
+        dscores = [w["os"][i, :counts[i]].clone() for i in range(N)]
+        if return_prior_index:
+            return boxes, labels, dscores, [w["op"][i, :counts[i]].clone() for i in range(N)]
+        return boxes, labels, dscores
+
+    # -- steps ------------------------------------------------------------------------------------------------
+    def _gt_warnings(self, gt_boxes, subjects):
+        for i, subj_boxes in enumerate(gt_boxes):  # ssd3d.py:481-490
+            if subj_boxes.numel() == 0:
+                continue
+            sizes = (subj_boxes[:, 3:] - subj_boxes[:, :3]).cpu()
+            for axis in (0, 1, 2):
+                negatives = int((sizes[:, axis] < 0).sum())
+                zeros = int((sizes[:, axis] == 0).sum())
+                if negatives > 0:
+                    warnings.warn(f"Given boxes has invalid values (subject {subjects[i]}). The box size must "
+                                  f"be non-negative but got {negatives} boxes with negative sizes.")
+                if zeros > 0:
+                    warnings.warn(f"Given boxes has invalid values (subject {subjects[i]}). The box size must "
+                                  f"be non-zero but got {zeros} boxes with size of zero.")
+
+    def _metrics(self, predicted_locs, predicted_scores, gt_boxes, gt_labels):
+        det_boxes, det_labels, det_scores = self.detect_objects(predicted_locs, predicted_scores, self.min_score,
+                                                                self.max_overlap, self.top_k)
+        if predicted_locs.size(1) <= 500:  # ssd3d.py:504-515
+            raise NotImplementedError
+        dif = [torch.zeros(l.size(0), dtype=torch.bool) for l in gt_labels]
+        m10 = calculate_mAP(det_boxes, det_labels, det_scores, gt_boxes, gt_labels, dif, min_overlap=0.1, return_detail=True)
+        m50 = calculate_mAP(det_boxes, det_labels, det_scores, gt_boxes, gt_labels, dif, min_overlap=0.5, return_detail=True)
+        return m10, m50
+
+    def training_step(self, batch, batch_idx=None):
+        """ssd3d.py:467-531."""
+        dev = self.device
+        images = batch["img"].to(dev)
+        gt_boxes = [b.to(dev) for b in batch["boxes"]]
+        gt_labels = [l.to(dev) for l in batch["labels"]]
+        predicted_locs, predicted_scores = self(images)
+        self._gt_warnings(gt_boxes, batch.get("subject", list(range(len(gt_boxes)))))
+        conf_loss, loc_loss = self.loss_fn(predicted_locs, predicted_scores, gt_boxes, gt_labels)
+        loss = conf_loss + self.loss_fn.alpha * loc_loss
+        logs = {"train_total_loss": loss, "train_conf_loss": conf_loss, "train_loc_loss": loc_loss}
+        if self.current_epoch % (self.compute_metric_every_n_epochs * 2) == 0:
+            with torch.no_grad():
+                logs["metrics_10"], logs["metrics_50"] = self._metrics(predicted_locs, predicted_scores, gt_boxes, gt_labels)
+        self.log('total_loss/training', loss.item())
+        self.log('confidence_loss/training', conf_loss.item())
+        self.log('localization_loss/training', loc_loss.item())
+        sch = self.lr_schedulers()
+        if sch is not None:
+            sch.step()
+        return {'loss': loss, "log": logs}
+
+    def validation_step(self, batch, batch_idx=None):
+        """ssd3d.py:533-586."""
+        dev = self.device
+        images = batch["img"].to(dev)
+        gt_boxes, gt_labels = batch["seg"] if "seg" in batch else (batch["boxes"], batch["labels"])
+        gt_boxes = [b.to(dev) for b in gt_boxes]
+        gt_labels = [l.to(dev) for l in gt_labels]
+        with torch.no_grad():
+            predicted_locs, predicted_scores = self(images)
+            self._gt_warnings(gt_boxes, batch.get("subject", list(range(len(gt_boxes)))))
+            conf_loss, loc_loss = self.loss_fn(predicted_locs, predicted_scores, gt_boxes, gt_labels)
+            loss = conf_loss + self.loss_fn.alpha * loc_loss
+            logs = {"val_total_loss": loss, "val_conf_loss": conf_loss, "val_loc_loss": loc_loss}
+            if self.current_epoch % self.compute_metric_every_n_epochs == 0:
+                m10, m50 = self._metrics(predicted_locs, predicted_scores, gt_boxes, gt_labels)
+                m50["mAP"] = torch.FloatTensor([m50["mAP"]])
+                logs["metrics_10"], logs["metrics_50"] = m10, m50
+        return {'val_loss': loss, "log": logs}
+
+    def predict_step(self, batch, batch_idx: int = 0, dataloader_idx: int = None):
+        """ssd3d.py:692-702."""
+        with torch.no_grad():
+            predicted_locs, predicted_scores = self(batch["img"].to(self.device))
+            return self.detect_objects(predicted_locs, predicted_scores, min_score=self.min_score,
+                                       max_overlap=self.max_overlap, top_k=self.top_k)
+
+    def configure_optimizers(self):
+        """ssd3d.py:704-722: Adam(weight_decay 5e-4), '.bias' parameters at 2*lr, cosine annealing T_max=40."""
+        from .optim import CosineAnnealingLR, FusedAdam
+        optimizer = FusedAdam(self, lr=self.lr, weight_decay=0.0005)
+        if self.scheduler != "none":
+            scheduler = CosineAnnealingLR(optimizer, T_max=40)
+            return [optimizer], [scheduler]
+        return optimizer
+
+    def compute_parameters_median_size(self):
+        with torch.no_grad():
+            return sum(abs(p).sum() for p in self.parameters())
+
+    # -- checkpoints (Lightning-compatible dict) ------------------------------------------------------
+    def save_checkpoint(self, path, optimizer=None):
+        ckpt = {"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
+                "hyper_parameters": dict(self.hparams), "epoch": self.current_epoch, "global_step": self.global_step}
+        if optimizer is not None:
+            ckpt["optimizer_states"] = [optimizer.state_dict()]
+        torch.save(ckpt, path)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, map_location="cpu", **overrides):
+        try:
+            ckpt = torch.load(path, map_location=map_location, weights_only=True)
+        except Exception:
+            # own checkpoints carry a plain dict of hyper-parameters (np.float64 scales etc.)
+            ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        hp = dict(ckpt.get("hyper_parameters", {}))
+        hp.update(overrides)
+        hp = {k: v for k, v in hp.items() if k in cls.__init__.__code__.co_varnames}
+        model = cls(**hp)
+        model.load_state_dict(ckpt["state_dict"])
+        model.current_epoch = int(ckpt.get("epoch", 0))
+        model.global_step = int(ckpt.get("global_step", 0))
+        return model
+
+
+class _MultiBoxLossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, loss_mod, locs, scores, gt_boxes, gt_labels, obj_off, total_objects):
+        st = loss_mod._state(locs.shape[0], locs.shape[1], scores.shape[2], total_objects, locs.device)
+        locs_c, scores_c = locs.contiguous().float(), scores.contiguous().float()
+        loss_mod._run_forward(st, locs_c, scores_c, gt_boxes, gt_labels, obj_off, total_objects)
+        ctx.loss_mod, ctx.st = loss_mod, st
+        ctx.save_for_backward(locs_c, scores_c)
+        out = st["loss_out"]
+        return out[0].clone(), out[1].clone()
+
+    @staticmethod
+    def backward(ctx, g_conf, g_loc):
+        locs, scores = ctx.saved_tensors
+        st = ctx.st
+        st["upstream"].copy_(torch.stack([g_conf.reshape(()), g_loc.reshape(())]))
+        N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
+        _lib.call("msl_multibox_loss_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
+                  ptr(st["loss_out"]), ptr(st["upstream"]), ptr(st["dlocs"]), ptr(st["dscores"]), N, P, ncls, _stream())
+        return None, st["dlocs"].clone(), st["dscores"].clone(), None, None, None, None
+
+
+class MultiBoxLoss(nn.Module):
+    """The MultiBox loss (ssd3d.py:741-941): prior<->object matching + target encoding + confidence (cross
+    entropy over all non-ignored priors / number of positives) + localisation (mean |.| over positives) loss."""
+
+    def __init__(self, priors_cxcycz, threshold=0.5, neg_pos_ratio=3, alpha=1.):
+        super(MultiBoxLoss, self).__init__()
+        self.priors_cxcycz = priors_cxcycz
+        self.priors_xyz = None
+        self.threshold = threshold
+        self.neg_pos_ratio = neg_pos_ratio
+        self.alpha = alpha
+        if type(self.threshold) == list:  # ssd3d.py:762-773
+            if len(self.threshold) == 1:
+                self.thresholding_mode = "hard"
+                self.threshold = self.threshold[0]
+            else:
+                self.thresholding_mode = "soft"
+                assert (len(self.threshold) == 2)
+        elif type(self.threshold) == float:
+            self.thresholding_mode = "hard"
+        else:
+            raise Exception(
+                f"Type error. Expected float or list of floats for threshold but got {type(self.threshold)}")
+        self._states = {}
+
+    def set_priors(self, priors_cxcycz):
+        self.priors_cxcycz = priors_cxcycz
+        self.priors_xyz = None
+
+    def _state(self, N, P, ncls, total_objects, dev):
+        key = (N, P, ncls, dev)
+        st = self._states.get(key)
+        if st is None:
+            f32, i32, i64 = torch.float32, torch.int32, torch.int64
+            L = _lib.load()
+            st = dict(overlap=torch.zeros((N, P), dtype=f32, device=dev), obj=torch.zeros((N, P), dtype=i32, device=dev),
+                      prior_for_obj=torch.zeros(256, dtype=i32, device=dev),
+                      true_classes=torch.zeros((N, P), dtype=i64, device=dev),
+                      true_locs=torch.zeros((N, P, 6), dtype=f32, device=dev),
+                      matched=torch.zeros((N, P), dtype=i64, device=dev),
+                      ws=torch.zeros(L.msl_multibox_loss_workspace_bytes() // 8, dtype=torch.float64, device=dev),
+                      loss_out=torch.zeros(3, dtype=f32, device=dev), upstream=torch.ones(2, dtype=f32, device=dev),
+                      dlocs=torch.zeros((N, P, 6), dtype=f32, device=dev),
+                      dscores=torch.zeros((N, P, ncls), dtype=f32, device=dev))
+            self._states[key] = st
+        if st["prior_for_obj"].numel() < total_objects:
+            st["prior_for_obj"] = torch.zeros(2 * total_objects, dtype=torch.int32, device=dev)
+        return st
+
+    @staticmethod
+    def pack_targets(boxes, labels, dev):
+        """list[(n_i,6)], list[(n_i,)] -> concatenated boxes (T,6) f32, labels (T,) i64, offsets (N+1,) i32, T."""
+        sizes = [int(b.shape[0]) for b in boxes]
+        offs = np.zeros(len(sizes) + 1, dtype=np.int32)
+        offs[1:] = np.cumsum(sizes)
+        T = int(offs[-1])
+        if T > 0:
+            gb = torch.cat([b.reshape(-1, 6) for b in boxes], 0).to(device=dev, dtype=torch.float32).contiguous()
+            gl = torch.cat([l.reshape(-1) for l in labels], 0).to(device=dev, dtype=torch.int64).contiguous()
+        else:
+            gb = torch.zeros((1, 6), dtype=torch.float32, device=dev)
+            gl = torch.zeros(1, dtype=torch.int64, device=dev)
+        return gb, gl, torch.from_numpy(offs).to(dev), T
+
+    def _thresholds(self):
+        if self.thresholding_mode == "hard":
+            return float(self.threshold), 0.0, 0
+        return float(self.threshold[0]), float(self.threshold[1]), 1
+
+    def _run_forward(self, st, locs, scores, gt_boxes, gt_labels, obj_off, T):
+        N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
+        assert P == self.priors_cxcycz.size(0) == scores.size(1)  # ssd3d.py:845
+        lo, hi, soft = self._thresholds()
+        sm = _stream()
+        _lib.call("msl_multibox_match", ptr(gt_boxes), ptr(gt_labels), ptr(obj_off), T, ptr(self.priors_cxcycz), N, P, lo,
+                  hi, soft, ptr(st["overlap"]), ptr(st["obj"]), ptr(st["prior_for_obj"]), ptr(st["true_classes"]),
+                  ptr(st["true_locs"]), ptr(st["matched"]), sm)
+        _lib.call("msl_multibox_loss_fwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
+                  ptr(st["ws"]), ptr(st["loss_out"]), N, P, ncls, sm)
+
+    def match(self, boxes, labels, n_classes=2):
+        """Matching only -> (true_classes (N,P) int64, true_locs (N,P,6), matched object (N,P) int64)."""
+        dev = self.priors_cxcycz.device
+        gb, gl, off, T = self.pack_targets(boxes, labels, dev)
+        N, P = len(boxes), self.priors_cxcycz.size(0)
+        st = self._state(N, P, n_classes, T, dev)
+        lo, hi, soft = self._thresholds()
+        _lib.call("msl_multibox_match", ptr(gb), ptr(gl), ptr(off), T, ptr(self.priors_cxcycz), N, P, lo, hi, soft,
+                  ptr(st["overlap"]), ptr(st["obj"]), ptr(st["prior_for_obj"]), ptr(st["true_classes"]),
+                  ptr(st["true_locs"]), ptr(st["matched"]), _stream())
+        return st["true_classes"].clone(), st["true_locs"].clone(), st["matched"].clone()
+
+    def forward(self, predicted_locs, predicted_scores, boxes, labels):
+        """-> (conf_loss, loc_loss) scalars (ssd3d.py:775-941)."""
+        if not predicted_locs.is_cuda:
+            raise _lib.HipKernelError("MultiBoxLoss runs on the HIP device only (no CPU fallback)")
+        if self.priors_cxcycz is None:
+            raise RuntimeError("MultiBoxLoss has no priors (model constructed without a GPU and never run)")
+        gb, gl, off, T = self.pack_targets(boxes, labels, predicted_locs.device)
+        conf_loss, loc_loss = _MultiBoxLossFunction.apply(self, predicted_locs, predicted_scores, gb, gl, off, T)
+        if torch.isnan(loc_loss):  # ssd3d.py:938-940 (batch without a single positive prior)
+            raise Exception("Loss is NaN")
+        return conf_loss, loc_loss

@@ -1,0 +1,82 @@
+"""Minimal training / prediction loops replacing PyTorch-Lightning's ``Trainer`` (reference ``train.py:171-188``,
+``predict.py:257-263``) for the one model of this repository.
+
+``FusedTrainer.step`` is the hot loop of the headline metric (training volumes/s): forward -> matching ->
+MultiBox loss -> closed-form loss gradient -> backward -> (RCCL bucketed all-reduce, overlapped) -> fused Adam
+-> cosine LR step, as one fixed sequence of C-ABI launches with no host synchronisation inside
+(ssd3d.py:467-531 + :704-722).  ``LSSD3D.training_step`` + ``loss.backward()`` + ``optimizer.step()`` is the
+API-compatible (autograd) route through the same kernels.
+"""
+import torch
+
+from . import _lib
+from ._lib import ptr
+from .optim import CosineAnnealingLR, FusedAdam
+from .parallel import GradBucketReducer
+from .ssd3d import MultiBoxLoss
+
+
+class FusedTrainer:
+    def __init__(self, model, lr=None, n_buckets=3, process_group=None):
+        self.model = model
+        self.opt = FusedAdam(model, lr=model.lr if lr is None else lr, weight_decay=0.0005)
+        self.sch = CosineAnnealingLR(self.opt, T_max=40) if model.scheduler != "none" else None
+        self.n_buckets, self.group = n_buckets, process_group
+        self.reducer = None
+        self.last_plan = None
+
+    def _reducer(self, arena):
+        if self.reducer is None or self.reducer.arena is not arena:
+            self.reducer = GradBucketReducer(arena, self.n_buckets, self.group)
+        return self.reducer
+
+    def step_packed(self, images, gt_boxes, gt_labels, obj_off, total_objects, sync=True):
+        """One optimisation step on already packed targets (see MultiBoxLoss.pack_targets).  With ``sync=False``
+        nothing is read back: the returned dict holds the device tensor ``loss_out`` = [conf, loc, n_positives]."""
+        m = self.model
+        if not images.is_cuda:
+            raise _lib.HipKernelError("FusedTrainer runs on the HIP device only (no CPU fallback)")
+        dev = images.device
+        m._ensure_device_state(dev)
+        eng = m._engine
+        arena = eng.ensure_arena(dev)
+        red = self._reducer(arena)
+        locs, scores = eng.forward(images, training=True, need_grad=True)
+        pl = eng.plan_for(images, True)
+        self.last_plan = pl
+        lf = m.loss_fn
+        N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
+        st = lf._state(N, P, ncls, total_objects, dev)
+        lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects)
+        if "upstream_alpha" not in st or st["upstream_alpha_value"] != float(lf.alpha):
+            st["upstream_alpha"] = torch.tensor([1.0, float(lf.alpha)], dtype=torch.float32, device=dev)  # loss = conf + alpha*loc
+            st["upstream_alpha_value"] = float(lf.alpha)
+        _lib.call("msl_multibox_loss_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
+                  ptr(st["loss_out"]), ptr(st["upstream_alpha"]), ptr(st["dlocs"]), ptr(st["dscores"]), N, P, ncls,
+                  torch.cuda.current_stream().cuda_stream)
+        eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red.on_stage)
+        scale = red.finish()
+        self.opt.step(grad_scale=scale, gather_autograd_grads=False)
+        if self.sch is not None:
+            self.sch.step()
+        m.global_step += 1
+        out = {"loss_out": st["loss_out"]}
+        if sync:
+            eng.check_nan(pl)
+            conf, loc, npos = st["loss_out"].tolist()
+            if loc != loc:  # ssd3d.py:938-940
+                raise Exception("Loss is NaN")
+            out.update(conf=conf, loc=loc, loss=conf + float(lf.alpha) * loc, n_positives=int(npos))
+        return out
+
+    def step(self, images, boxes, labels, sync=True):
+        gb, gl, off, T = MultiBoxLoss.pack_targets(boxes, labels, images.device)
+        return self.step_packed(images, gb, gl, off, T, sync=sync)
+
+    def state_dict(self):
+        return {"optimizer": self.opt.state_dict(), "scheduler": None if self.sch is None else self.sch.state_dict()}
+
+    def load_state_dict(self, sd):
+        self.opt.load_state_dict(sd["optimizer"])
+        if self.sch is not None and sd.get("scheduler") is not None:
+            self.sch.load_state_dict(sd["scheduler"])

@@ -1,0 +1,315 @@
+"""Model-level parity on a real MI355X, through the reference-shaped Python API (which calls the C ABI):
+the HIP path against the CPU oracle and against the golden vectors minted from the reference itself.
+Bar (BASELINE.json north_star): integer outputs bit-exact, fp32 regressions / losses within 1e-4."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import detect as OD
+from oracle import multibox as OMB
+from oracle.train_step import make_optimizer, train_step
+from tests.golden import cases, detinit
+from tests.util import golden, oracle_model
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+RTOL = 1e-4  # the tolerance north_star states for fp32 box regressions and losses
+
+
+def hip_model(cin=1, size=(64, 64, 64), threshold=None, seed=1234, **kw):
+    from mslesions3d_amd.ssd3d import LSSD3D
+    m = LSSD3D(n_classes=2, input_channels=cin, input_size=size, threshold=[0.1, 0.2] if threshold is None else threshold, **kw)
+    m.load_state_dict(detinit.fill_state_dict(m.state_dict(), seed))
+    return m.to(DEV)
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def assert_close(a, b, tol, what):
+    e = relerr(a, b)
+    assert e <= tol, f"{what}: max abs err / max |ref| = {e:.3e} > {tol:.1e}"
+
+
+# ------------------------------------------------------------------------------------------------- priors / boxes
+@pytest.mark.parametrize("tag,size", [("64", (64, 64, 64)), ("128", (128, 128, 128)), ("192", (192, 192, 192)),
+                                      ("48x64x64", (48, 64, 64))])
+def test_priors_bit_exact(tag, size):
+    g = golden("priors")
+    m = hip_model(size=size)
+    p = m.priors_cxcycz.cpu().numpy()
+    assert p.shape[0] == int(g[f"n_{tag}"])
+    assert hashlib.sha256(p.tobytes()).digest() == bytes(g[f"sha256_{tag}"])
+    assert np.array_equal(p[::97], g[f"stride97_{tag}"])
+    per = m.create_prior_boxes(per_feature_map=True)
+    assert list(per.keys()) == [3, 5, 7] and sum(len(v) for v in per.values()) == p.shape[0]
+
+
+def test_box_utils_golden():
+    from mslesions3d_amd import utils as U
+    g = golden("boxmath")
+    a, b, gg = (t.to(DEV) for t in cases.boxmath_inputs())
+    ac, bc = U.xyz_to_cxcycz(a), U.xyz_to_cxcycz(b)
+    bc[:, 3:] = bc[:, 3:].clamp(min=1e-3)
+    assert np.array_equal(ac.cpu().numpy(), g["xyz_to_cxcycz"])
+    assert np.array_equal(U.cxcycz_to_xyz(ac).cpu().numpy(), g["cxcycz_to_xyz"])
+    assert np.array_equal(U.find_intersection3d(a, b).cpu().numpy(), g["intersection"])
+    assert np.array_equal(U.find_jaccard_overlap3d(a, b).cpu().numpy(), g["iou"], equal_nan=True)
+    assert np.array_equal(U.find_jaccard_overlap3d(a, a).cpu().numpy(), g["iou_self"], equal_nan=True)
+    # log / exp differ from the CPU libm in the last ulp: 1e-6 relative
+    np.testing.assert_allclose(U.cxcycz_to_gcxgcygcz(U.xyz_to_cxcycz(b[2:26]), bc[14:38]).cpu().numpy(), g["encode"],
+                               rtol=2e-6, atol=1e-6, equal_nan=True)
+    np.testing.assert_allclose(U.gcxgcygcz_to_cxcycz(gg, bc).cpu().numpy(), g["decode"], rtol=2e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------------------------------------- matching + loss
+@pytest.mark.parametrize("name", list(cases.matching_cases().keys()))
+def test_matching_and_loss_golden(name):
+    from mslesions3d_amd.ssd3d import MultiBoxLoss
+    g = golden("matching")
+    c = cases.matching_cases()[name]
+    m = hip_model()
+    loss_fn = MultiBoxLoss(m.priors_cxcycz, threshold=c["threshold"], alpha=1.0)
+    boxes = [b.to(DEV) for b in c["boxes"]]
+    labels = [l.to(DEV) for l in c["labels"]]
+    tc, tl, matched = loss_fn.match(boxes, labels)
+    assert np.array_equal(tc.cpu().numpy().astype(np.int8), g[f"{name}__true_classes"]), "true_classes must be bit-exact"
+    otc, otl, omatched = OMB.match_batch(c["boxes"], c["labels"], m.priors_cxcycz.cpu(), c["threshold"])
+    assert torch.equal(matched.cpu(), omatched), "matched object index per prior must be bit-exact"
+    np.testing.assert_allclose(tl.cpu().numpy(), g[f"{name}__true_locs"], rtol=2e-6, atol=2e-6)
+    locs, scores = detinit.make_head_outputs(c["head_seed"], len(boxes), cases.P_C64)
+    locs, scores = locs.to(DEV).requires_grad_(True), scores.to(DEV).requires_grad_(True)
+    conf, loc = loss_fn(locs, scores, boxes, labels)
+    (conf + loc).backward()
+    np.testing.assert_allclose(conf.item(), float(g[f"{name}__conf"]), rtol=RTOL)
+    np.testing.assert_allclose(loc.item(), float(g[f"{name}__loc"]), rtol=RTOL)
+    pos = tc.cpu().numpy() > 0
+    np.testing.assert_allclose(locs.grad.cpu().numpy()[pos], g[f"{name}__dlocs_nz"], rtol=RTOL, atol=1e-9)
+    assert float(locs.grad.cpu()[~torch.from_numpy(pos)].abs().max()) == 0.0
+    np.testing.assert_allclose(scores.grad.cpu().numpy().reshape(-1)[::17], g[f"{name}__dscores_s17"], rtol=RTOL, atol=1e-8)
+
+
+def test_empty_gt_batch_raises():
+    m = hip_model()
+    locs, scores = (t.to(DEV) for t in detinit.make_head_outputs(1, 2, cases.P_C64))
+    with pytest.raises(Exception, match="NaN"):
+        m.loss_fn(locs, scores, [torch.zeros((0, 6), device=DEV)] * 2, [torch.zeros((0,), dtype=torch.long, device=DEV)] * 2)
+
+
+def test_cpu_input_fails_loudly():
+    from mslesions3d_amd._lib import HipKernelError
+    m = hip_model()
+    with pytest.raises(HipKernelError, match="no CPU fallback"):
+        m(torch.zeros(1, 1, 64, 64, 64))
+
+
+# ------------------------------------------------------------------------------------------------- network
+@pytest.mark.parametrize("tag,n,cin,size,stride", [("c64", 2, 1, (64, 64, 64), 7), ("a2_2ch64", 2, 2, (64, 64, 64), 7),
+                                                    ("noncube", 2, 1, (48, 64, 64), 7), ("a128", 4, 1, (128, 128, 128), 61)])
+def test_network_forward_backward_golden(tag, n, cin, size, stride):
+    g = golden(f"network_{tag}")
+    m = hip_model(cin, size)
+    x = detinit.make_volume_batch(5, n, cin, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, n, size)
+    m.eval()
+    with torch.no_grad():
+        le, se = m(x)
+    assert_close(le.reshape(-1)[::stride], torch.from_numpy(g["eval_locs"]), RTOL, "eval locs")
+    assert_close(se.reshape(-1)[::stride], torch.from_numpy(g["eval_scores"]), RTOL, "eval scores")
+    m.train()
+    locs, scores = m(x)
+    assert_close(locs.reshape(-1)[::stride], torch.from_numpy(g["train_locs"]), RTOL, "train locs")
+    assert_close(scores.reshape(-1)[::stride], torch.from_numpy(g["train_scores"]), RTOL, "train scores")
+    conf, loc = m.loss_fn(locs, scores, [b.to(DEV) for b in boxes], [l.to(DEV) for l in labels])
+    np.testing.assert_allclose(conf.item(), float(g["conf"]), rtol=RTOL)
+    np.testing.assert_allclose(loc.item(), float(g["loc"]), rtol=RTOL)
+    (conf + m.loss_fn.alpha * loc).backward()
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert list(grads.keys()) == list(g["grad_names"])  # rescale_factors stays grad-less
+    norms = np.array([v.double().norm().item() for v in grads.values()])
+    bad = [(k, a, b) for k, a, b in zip(grads, norms, g["grad_norm"]) if abs(a - b) > 2e-3 * abs(b) + 1e-7]
+    assert not bad, f"gradient norms off (name, hip, reference): {bad[:6]}"
+    sd = m.state_dict()
+    for k in ("base.features.0.1", "base.features.1.bn1", "base.features.4.bn2", "base.features.7.bn2"):
+        np.testing.assert_allclose(sd[k + ".running_mean"].cpu().numpy(), g[f"rm__{k}"], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(sd[k + ".running_var"].cpu().numpy(), g[f"rv__{k}"], rtol=1e-4, atol=1e-6)
+        assert int(sd[k + ".num_batches_tracked"]) == 1
+
+
+def test_full_gradients_against_oracle():
+    """Every gradient element (not only norms) against CPU autograd of the oracle, 64^3 x 2."""
+    size, n = (64, 64, 64), 2
+    m, o = hip_model(1, size), oracle_model(1, size)
+    x = detinit.make_volume_batch(5, n, 1, size)
+    boxes, labels = detinit.make_gt(8, n, size)
+    o.train()
+    ol, osc = o(x)
+    oc, olc = OMB.multibox_loss(ol, osc, boxes, labels, o.priors_cxcycz, [0.1, 0.2])
+    (oc + olc).backward()
+    m.train()
+    l, s = m(x.to(DEV))
+    assert_close(l, ol, RTOL, "locs")
+    assert_close(s, osc, RTOL, "scores")
+    c, lc = m.loss_fn(l, s, [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels])
+    (c + lc).backward()
+    og = dict((k, p.grad) for k, p in o.named_parameters())
+    worst = []
+    for k, p in m.named_parameters():
+        if og[k] is None:
+            assert p.grad is None
+            continue
+        worst.append((relerr(p.grad, og[k]), k))
+    worst.sort(reverse=True)
+    assert worst[0][0] <= 2e-3, f"largest relative gradient errors: {worst[:5]}"
+
+
+def test_two_adam_steps_golden():
+    g = golden("network_c64")
+    size, n = (64, 64, 64), 2
+    m = hip_model(1, size, lr=1e-3)
+    m.train()
+    [opt], [sch] = m.configure_optimizers()
+    losses = []
+    for step in range(2):
+        xs = detinit.make_volume_batch(50 + step, n, 1, size).to(DEV)
+        bs, ls = detinit.make_gt(60 + step, n, size)
+        opt.zero_grad()
+        lo, sc = m(xs)
+        cf, lc = m.loss_fn(lo, sc, [b.to(DEV) for b in bs], [t.to(DEV) for t in ls])
+        loss = cf + m.loss_fn.alpha * lc
+        loss.backward()
+        opt.step()
+        sch.step()
+        losses.append([loss.item(), cf.item(), lc.item()])
+    np.testing.assert_allclose(np.array(losses), g["adam_losses"], rtol=5e-4)
+    np.testing.assert_allclose(sch.get_last_lr(), g["adam_lr"], rtol=1e-9)
+    names = [k for k, _ in m.named_parameters()]
+    assert names == list(g["adam_param_names"])
+    norms = np.array([p.detach().double().norm().item() for _, p in m.named_parameters()])
+    np.testing.assert_allclose(norms, g["adam_param_norm"], rtol=1e-4)
+
+
+def test_fused_step_equals_autograd_step():
+    """The graph-friendly fused training step and the autograd API path run the same kernels -> same parameters."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (64, 64, 64), 2
+    xs = detinit.make_volume_batch(50, n, 1, size).to(DEV)
+    bs, ls = detinit.make_gt(60, n, size)
+    a = hip_model(1, size, lr=1e-3)
+    a.train()
+    [opt], [sch] = a.configure_optimizers()
+    lo, sc = a(xs)
+    cf, lc = a.loss_fn(lo, sc, [b.to(DEV) for b in bs], [t.to(DEV) for t in ls])
+    (cf + a.loss_fn.alpha * lc).backward()
+    opt.step()
+    b = hip_model(1, size, lr=1e-3)
+    b.train()
+    tr = FusedTrainer(b)
+    out = tr.step(xs, bs, ls)
+    np.testing.assert_allclose(out["conf"], cf.item(), rtol=1e-6)
+    np.testing.assert_allclose(out["loc"], lc.item(), rtol=1e-6)
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), f"{k} differs between the autograd and the fused step"
+
+
+def test_determinism_run_to_run():
+    size, n = (64, 64, 64), 2
+    x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, n, size)
+    outs = []
+    for _ in range(2):
+        m = hip_model(1, size)
+        m.train()
+        l, s = m(x)
+        c, lc = m.loss_fn(l, s, [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels])
+        (c + lc).backward()
+        outs.append((l.clone(), s.clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None])))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b), "two identical runs must be bit-identical (no float atomics anywhere)"
+
+
+def test_standalone_submodules_match_fused_forward():
+    size, n = (64, 64, 64), 2
+    m = hip_model(1, size)
+    x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
+    m.eval()
+    with torch.no_grad():
+        l, s = m(x)
+        feats = m.base(x)
+        l2, s2 = m.pred_convs(feats)
+    assert list(feats.keys()) == [3, 5, 7]
+    assert tuple(feats[3].shape) == (n, 128, 8, 8, 8) and tuple(feats[7].shape) == (n, 512, 2, 2, 2)
+    assert_close(l2, l, 1e-5, "stand-alone locs")
+    assert_close(s2, s, 1e-5, "stand-alone scores")
+
+
+def test_nan_input_raises():
+    m = hip_model()
+    x = torch.zeros(1, 1, 64, 64, 64, device=DEV)
+    x[0, 0, 3, 3, 3] = float("nan")
+    with pytest.raises(Exception, match="NaN|nan"):
+        m(x)
+
+
+# ------------------------------------------------------------------------------------------------- detection
+@pytest.mark.parametrize("name", list(cases.detect_cases().keys()))
+def test_detect_objects_golden(name):
+    g = golden("detect")
+    c = cases.detect_cases()[name]
+    m = hip_model()
+    locs, scores = cases.detect_inputs(c)
+    b, l, s, pi = m.detect_objects(locs.to(DEV), scores.to(DEV), c["min_score"], c["max_overlap"], c["top_k"],
+                                   return_prior_index=True)
+    ob, ol, osc, oi = OD.detect_objects(locs, scores, m.priors_cxcycz.cpu(), c["min_score"], c["max_overlap"], c["top_k"],
+                                        return_prior_index=True)
+    for i in range(c["n"]):
+        assert np.array_equal(l[i].cpu().numpy(), g[f"{name}__labels_{i}"])
+        if c["quantized"] or name == "none_found":
+            # exact ties / no near-ties: the keep-list is decided by the stable order -> bit-exact
+            assert torch.equal(pi[i].cpu(), oi[i]), "keep-list (prior indices) must be bit-exact"
+        else:
+            # exp() differs from the CPU libm in the last ulp, which may swap two near-equal scores
+            assert set(pi[i].cpu().tolist()) == set(oi[i].tolist())
+        np.testing.assert_allclose(s[i].cpu().numpy(), g[f"{name}__scores_{i}"], rtol=1e-5, atol=1e-7)
+        order_h = np.argsort(pi[i].cpu().numpy(), kind="stable")
+        order_o = np.argsort(oi[i].numpy(), kind="stable")
+        np.testing.assert_allclose(b[i].cpu().numpy()[order_h], ob[i].numpy()[order_o], rtol=1e-5, atol=1e-6)
+
+
+def test_nms_keep_list_bit_exact_on_shared_probabilities():
+    """Feed the oracle the GPU's own softmax output (as logits log p) so both sides see identical scores:
+    then every index — order, suppression, top-k — must agree exactly at full size (P = 9344, 128^3)."""
+    m = hip_model(size=(128, 128, 128))
+    P = m.priors_cxcycz.shape[0]
+    locs, scores = detinit.make_head_outputs(77, 2, P, loc_std=0.6, score_std=2.5)
+    locs = (locs * 8).round() / 8
+    scores[..., 0] = 0
+    scores[..., 1] = (scores[..., 1] * 4).round() / 4
+    b, l, s, pi = m.detect_objects(locs.to(DEV), scores.to(DEV), 0.3, 0.45, 100, return_prior_index=True)
+    ob, ol, osc, oi = OD.detect_objects(locs, scores, m.priors_cxcycz.cpu(), 0.3, 0.45, 100, return_prior_index=True)
+    for i in range(2):
+        assert torch.equal(pi[i].cpu(), oi[i])
+        assert torch.equal(l[i].cpu(), ol[i])
+
+
+def test_training_validation_predict_steps():
+    size, n = (64, 64, 64), 2  # P = 1168 > 500 so mAP is computed (ssd3d.py:504)
+    m = hip_model(1, size, lr=1e-3, min_score=0.3)
+    boxes, labels = detinit.make_gt(8, n, size)
+    batch = {"img": detinit.make_volume_batch(5, n, 1, size), "boxes": boxes, "labels": labels, "seg": [boxes, labels],
+             "subject": ["0000", "0001"]}
+    m.train()
+    out = m.training_step(batch)
+    assert set(out.keys()) == {"loss", "log"} and out["loss"].requires_grad
+    assert {"train_total_loss", "train_conf_loss", "train_loc_loss", "metrics_10", "metrics_50"} <= set(out["log"].keys())
+    assert set(m.logged) == {"total_loss/training", "confidence_loss/training", "localization_loss/training"}
+    out["loss"].backward()
+    m.eval()
+    v = m.validation_step(batch, 0)
+    assert "val_loss" in v and "metrics_50" in v["log"]
+    p = m.predict_step(batch, 0)
+    assert len(p) == 3 and len(p[0]) == n and p[0][0].shape[1] == 6
