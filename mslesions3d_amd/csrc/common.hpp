@@ -46,7 +46,12 @@ __device__ __forceinline__ double block_sum(double v, double* scratch) {
 
 // relu(x * s + t) when affine is requested, else x.  fmaf is what every consumer uses, so all
 // kernels that re-create an activation from (raw conv output, scale, shift) agree bit for bit.
-__device__ __forceinline__ float act(float x, float s, float t) { return fmaxf(fmaf(x, s, t), 0.0f); }
+// NaN must survive the ReLU (torch's relu propagates it; fmaxf would swallow it and hide a diverged run from
+// the NaN guards of ssd3d.py:95-98,:258-261).
+__device__ __forceinline__ float act(float x, float s, float t) {
+  const float v = fmaf(x, s, t);
+  return v < 0.0f ? 0.0f : v;
+}
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
