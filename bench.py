@@ -1,0 +1,176 @@
+"""Headline benchmark: training volumes/s of the 3D-SSD step at 128^3, batch 4 per GPU, fp32 (BASELINE.json).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + matching + MultiBox loss + backward + (RCCL gradient all-reduce) + fused Adam + cosine LR
+step on one resident synthetic batch (``mslesions3d_amd.trainer.FusedTrainer.step_packed``) — nothing is skipped.
+Prints ONE JSON line on rank 0 with the whole-job throughput, the roofline of the dominant kernel (the stride-2
+depthwise forward of block 1, timed with HIP events on its launch stream inside the timed steps) and a CPU
+baseline (the oracle's train step on this box's host cores, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 achievable
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=4, help="volumes per GPU")
+    ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch and print a table (stderr)")
+    return ap.parse_args()
+
+
+def cpu_baseline(size, batch, channels, steps):
+    """The oracle (CPU restatement of the reference, kind 'port') timed on the host cores: 1 warm-up + `steps`."""
+    from oracle.network import OracleSSD3D
+    from oracle.train_step import make_optimizer, train_step
+    from mslesions3d_amd.synth import make_case
+    import numpy as np
+    torch.manual_seed(970205)
+    # the GPU box exposes every host core but a 1-GPU job owns a 16-core share: more threads only thrash
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(cores)
+    model = OracleSSD3D(2, channels, (size,) * 3, emulate_reference_init=False).train()
+    opt, sch = make_optimizer(model, 1e-3)
+    imgs, boxes, labels = [], [], []
+    for i in range(batch):
+        img, _, b, l = make_case(i, (size,) * 3)
+        imgs.append(np.stack([img] * channels))
+        boxes.append(torch.from_numpy(b))
+        labels.append(torch.from_numpy(l))
+    x = torch.from_numpy(np.stack(imgs))
+    train_step(model, opt, sch, x, boxes, labels, [0.1, 0.2])
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        train_step(model, opt, sch, x, boxes, labels, [0.1, 0.2])
+    dt = time.perf_counter() - t0
+    return {"value": round(batch * steps / dt, 3), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{steps} timed train steps (+1 warm-up) of the same {size}^3 batch-{batch} fp32 workload, "
+                      f"oracle (plain torch CPU ops), {dt / steps * 1e3:.0f} ms/step"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from mslesions3d_amd.parallel import broadcast_model
+    from mslesions3d_amd.ssd3d import LSSD3D, MultiBoxLoss
+    from mslesions3d_amd.synth import make_batch_on_device
+    from mslesions3d_amd.trainer import FusedTrainer
+
+    size = (args.size,) * 3
+    torch.manual_seed(970205)  # train.py:61
+    model = LSSD3D(n_classes=2, input_channels=args.channels, input_size=size, threshold=[0.1, 0.2], alpha=1.0, lr=1e-3,
+                   batch_size=args.batch).to(dev).train()
+    model._ensure_device_state(dev)
+    model._engine.ensure_arena(dev)
+    broadcast_model(model)
+    trainer = FusedTrainer(model)
+
+    # a small pool of resident batches (different volumes per rank: weak scaling, independent shards)
+    pool = []
+    for k in range(4):
+        x, boxes, labels = make_batch_on_device(args.batch, size, dev, args.channels, seed=1000 * rank + k)
+        pool.append((x,) + MultiBoxLoss.pack_targets(boxes, labels, dev))
+
+    def run(nsteps):
+        for s in range(nsteps):
+            x, gb, gl, off, T = pool[s % len(pool)]
+            trainer.step_packed(x, gb, gl, off, T, sync=False)
+
+    run(args.warmup)
+    torch.cuda.synchronize()
+    eng = model._engine
+    eng.start_profile(None if args.profile_all else {"dw_fwd1"})
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.stop_profile()
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    # sanity: the last step produced finite losses (one sync, outside the timed region)
+    pl = trainer.last_plan
+    eng.check_nan(pl)
+    conf, loc, npos = model.loss_fn._state(args.batch, pl.P, 2, 0, dev)["loss_out"].tolist()
+    assert conf == conf and loc == loc and npos > 0, (conf, loc, npos)
+
+    if rank == 0:
+        value = world * args.batch * args.steps / dt
+        # dominant kernel: depthwise forward of block 1 (stride 2): input (N,32,S0) read once + output written once + weights
+        C1 = 32
+        d0 = pl.dims[0]
+        d1 = pl.dims[1]
+        alg_bytes = 4.0 * (args.batch * C1 * (d0[0] * d0[1] * d0[2] + d1[0] * d1[1] * d1[2]) + C1 * 27)
+        ms = prof.get("dw_fwd1", [])
+        avg_ms = sum(ms) / max(len(ms), 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if ms else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "dw_fwd1_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        out = {
+            "metric": "training volumes/sec at 128^3 batch-4 (fwd+loss+bwd+Adam), data-parallel over N MI355X",
+            "value": round(value, 2), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.size}^3 synthetic volumes, batch {args.batch}/GPU, {args.channels} channel(s), fp32, "
+                                   f"SSD3D+MobileNet3D full train step (BASELINE configs[1]/[2] shape)",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}", "priors": pl.P,
+                       "last_loss": {"conf": conf, "loc": loc, "n_positives": npos}},
+            "roofline": {"bound": "hbm", "kernel": "dw_fwd_stream_kernel<2,1,4> (depthwise 3x3x3 s2 forward, block 1)",
+                         "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": len(ms)},
+        }
+        if args.profile_all:
+            rows = sorted(((sum(v) / len(v), t, len(v)) for t, v in prof.items()), reverse=True)
+            tot = sum(r[0] for r in rows)
+            print(f"per-launch HIP-event times (avg ms per step), total {tot:.3f} ms", file=sys.stderr)
+            for a, t, n in rows:
+                print(f"  {t:40s} {a * 1e3:9.1f} us  x{n}", file=sys.stderr)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.size, args.batch, args.channels, args.cpu_steps)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

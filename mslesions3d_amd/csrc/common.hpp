@@ -55,4 +55,36 @@ __device__ __forceinline__ float act(float x, float s, float t) {
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+
+// out[i] = sum_k slabs[k * stride + i], k = 0..nslabs-1.  32 outputs x 8 slab groups per workgroup; every thread
+// walks its slabs with independent loads (deep memory-level parallelism), then the 8 group sums are folded
+// in a fixed order -> bit-reproducible.  Launch with cdiv(count, 32) workgroups of 256 threads.
+__device__ __forceinline__ float reduce_slabs_256(const float* __restrict__ slabs, size_t stride, int count,
+                                                  int nslabs, float* lds /* [8][33] */) {
+  const int li = threadIdx.x & 31, g = threadIdx.x >> 5;
+  const int i = blockIdx.x * 32 + li;
+  float s = 0.f;
+  if (i < count) {
+    const float* p = slabs + i;
+    int k = g;
+#pragma unroll 1
+    for (; k + 56 < nslabs; k += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 8 * u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < nslabs; k += 8) s += p[(size_t)k * stride];
+  }
+  lds[g * 33 + li] = s;
+  __syncthreads();
+  float t = 0.f;
+  if (g == 0) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += lds[u * 33 + li];
+  }
+  return t;  // valid for g == 0 && i < count
+}
+
 }  // namespace msl

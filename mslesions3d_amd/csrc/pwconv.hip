@@ -239,11 +239,10 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
 // out[i] = sum_k slabs[k][i], k ascending (fixed order)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                           int count, int nslabs) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  float s = 0.f;
-  for (int k = 0; k < nslabs; ++k) s += slabs[(size_t)k * count + i];
-  out[i] = s;
+  __shared__ float lds[8 * 33];
+  const float t = msl::reduce_slabs_256(slabs, (size_t)count, count, nslabs, lds);
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31);
+  if ((threadIdx.x >> 5) == 0 && i < count) out[i] = t;
 }
 
 struct BwPlan {
@@ -256,7 +255,7 @@ BwPlan bw_plan(int N, int Cin, int Cout, int S) {
   p.chunks_per_img = msl::cdiv(S, PC);
   const int total = N * p.chunks_per_img;
   const int tiles = (Cout / 64) * (Cin / p.bnn);
-  int ks = std::max(1, std::min(total, 1024 / std::max(1, tiles)));
+  int ks = std::max(1, std::min(total, 512 / std::max(1, tiles)));
   p.chunks_per_block = msl::cdiv(total, ks);
   p.ksplit = msl::cdiv(total, p.chunks_per_block);
   return p;
@@ -317,7 +316,7 @@ int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale
   }
   MSL_LAUNCH_CHECK();
   const int count = Cout * Cin;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(msl::cdiv(count, 256)), dim3(256), 0, st, workspace, dw, count, p.ksplit);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(msl::cdiv(count, 32)), dim3(256), 0, st, workspace, dw, count, p.ksplit);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

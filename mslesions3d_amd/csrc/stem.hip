@@ -218,12 +218,15 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
 
 __global__ __launch_bounds__(256) void stem_bwd_weight_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                                      int K, int NT, int nslabs) {
-  const int i = blockIdx.x * 256 + threadIdx.x;  // over 32*K
-  if (i >= 32 * K) return;
-  const int co = i / K, k = i % K;
-  float s = 0.f;
-  for (int b = 0; b < nslabs; ++b) s += slabs[(size_t)b * 32 * 32 * NT + co * (32 * NT) + k];
-  dw[i] = s;
+  __shared__ float lds[8 * 33];
+  // reduce the padded [32][32*NT] slab image, then drop the padding columns
+  const int count = 32 * 32 * NT;
+  const float t = msl::reduce_slabs_256(slabs, (size_t)count, count, nslabs, lds);
+  const int i = blockIdx.x * 32 + (threadIdx.x & 31);
+  if ((threadIdx.x >> 5) == 0 && i < count) {
+    const int co = i / (32 * NT), k = i % (32 * NT);
+    if (k < K) dw[co * K + k] = t;
+  }
 }
 
 constexpr int STEM_BW_BLOCKS = 512;
@@ -291,7 +294,7 @@ int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* 
 #undef MSL_STEM_BW
   MSL_LAUNCH_CHECK();
   const int K = Cin * 27;
-  hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * K, 256)), dim3(256), 0, st, workspace, dw, K,
+  hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw, K,
                      NT, nblocks);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

@@ -174,6 +174,7 @@ class Engine:
         self.model = model
         self.arena = None
         self.plans = {}
+        self.prof, self.prof_tags = None, None
         feats = model.base.features
         specs = []
         for i, f in enumerate(feats):
@@ -203,6 +204,28 @@ class Engine:
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream
+
+    # -- optional per-launch HIP-event timing (bench.py's roofline leg) -------------------------------------
+    def start_profile(self, tags=None):
+        """Record a HIP event pair (on the launch stream) around every tagged launch; tags=None -> all."""
+        self.prof, self.prof_tags = {}, (None if tags is None else set(tags))
+
+    def stop_profile(self):
+        """-> {tag: [ms, ...]} (synchronises)."""
+        torch.cuda.synchronize()
+        out = {t: [a.elapsed_time(b) for a, b in ev] for t, ev in (self.prof or {}).items()}
+        self.prof = None
+        return out
+
+    def _k(self, tag, name, *args):
+        if self.prof is None or (self.prof_tags is not None and tag not in self.prof_tags):
+            _lib.call(name, *args)
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.call(name, *args)
+        e1.record()
+        self.prof.setdefault(tag, []).append((e0, e1))
 
     def _bn_fwd(self, bn, vec, partials, NP, count, training, st):
         C = vec.shape[1]
@@ -240,7 +263,7 @@ class Engine:
         # stem (features[0] = Conv3d + BN + ReLU)
         D, H, W = pl.in_dims
         sd, sh, sw = specs[0]["stride"]
-        _lib.call("msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), pp, N, specs[0]["cin"], D, H, W,
+        self._k("stem_fwd", "msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), pp, N, specs[0]["cin"], D, H, W,
                   sd, sh, sw, st)
         od, oh, ow = pl.dims[0]
         self._bn_fwd(feats[0][1], pl.bn_y[0], part, L.msl_stem_conv_fwd_num_partials(N, od, oh, ow),
@@ -252,11 +275,11 @@ class Engine:
             D, H, W = pl.dims[i]
             S = D * H * W
             s = sp["stride"][0]
-            _lib.call("msl_dwconv_fwd", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
+            self._k(f"dw_fwd{i}", "msl_dwconv_fwd", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
                       ptr(blk.conv1.weight), ptr(pl.z[i]), pp, N, sp["cin"], pd, ph, pw, s, 0, st)
             self._bn_fwd(blk.bn1, pl.bn_z[i], part, L.msl_dwconv_fwd_num_partials(N, sp["cin"], pd, ph, pw, s),
                          N * S, training, st)
-            _lib.call("msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(blk.conv2.weight),
+            self._k(f"pw_fwd{i}", "msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(blk.conv2.weight),
                       ptr(pl.y[i]), pp, N, sp["cin"], sp["cout"], S, st)
             self._bn_fwd(blk.bn2, pl.bn_y[i], part, L.msl_pwconv_fwd_num_partials(N, S), N * S, training, st)
             if i in pl.fpad:
@@ -264,7 +287,7 @@ class Engine:
                 if want_features:
                     plain = torch.empty((N, sp["cout"], D, H, W), dtype=torch.float32, device=x.device)
                     out_feats[i] = plain
-                _lib.call("msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]), ptr(pl.bn_y[i][1]), ptr(plain),
+                self._k(f"materialize{i}", "msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]), ptr(pl.bn_y[i][1]), ptr(plain),
                           ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
         self._heads_forward(pl, st)
         _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
@@ -280,8 +303,8 @@ class Engine:
             lc, cc = m.pred_convs.loc_convs[k], m.pred_convs.cl_convs[k]
             C = self.layer_specs[f]["cout"]
             D, H, W = pl.dims[f]
-            _lib.call("msl_head_pack_weights", ptr(lc.weight), ptr(cc.weight), ptr(pl.Wf[f]), ptr(pl.Wb[f]), C, ncls, st)
-            _lib.call("msl_head_conv_fwd", ptr(pl.fpad[f]), ptr(pl.Wf[f]), ptr(lc.bias), ptr(cc.bias), ptr(pl.locs),
+            self._k(f"head_pack{f}", "msl_head_pack_weights", ptr(lc.weight), ptr(cc.weight), ptr(pl.Wf[f]), ptr(pl.Wb[f]), C, ncls, st)
+            self._k(f"head_fwd{f}", "msl_head_conv_fwd", ptr(pl.fpad[f]), ptr(pl.Wf[f]), ptr(lc.bias), ptr(cc.bias), ptr(pl.locs),
                       ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
 
     # ------------------------------------------------------------------------------------------------
@@ -290,11 +313,11 @@ class Engine:
         L = _lib.load()
         gv = self.arena.grad_views
         NP = L.msl_bn_relu_bwd_num_partials(N, S)
-        _lib.call("msl_bn_relu_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
+        self._k("bn_bwd_reduce:" + bn_name, "msl_bn_relu_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(pl.partials), N, C, S, st)
         _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(count), ptr(gv[bn_name + ".weight"]),
                   ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
-        _lib.call("msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
+        self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(vec[4]), ptr(vec[5]), ptr(g), N, C, S, st)
 
     def backward(self, pl, dlocs, dscores, on_bucket_ready=None):
@@ -314,13 +337,13 @@ class Engine:
         for k, f in enumerate(pl.feat_ids):
             C = specs[f]["cout"]
             D, H, W = pl.dims[f]
-            _lib.call("msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P, pl.prior_off[f],
+            self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P, pl.prior_off[f],
                       ncls, st)
             pre = f"pred_convs.loc_convs.{k}", f"pred_convs.cl_convs.{k}"
-            _lib.call("msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
+            self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
                       ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
                       ptr(pl.head_ws[f]), N, C, D, H, W, ncls, st)
-            _lib.call("msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W, ncls, st)
+            self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W, ncls, st)
         if on_bucket_ready:
             on_bucket_ready("heads")
         last = len(specs) - 1
@@ -335,17 +358,17 @@ class Engine:
                 raise RuntimeError("the last backbone feature must feed a head")
             # y_i = pw(relu(bn1(z_i))): BN2 backward, then the two GEMMs
             self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st)
-            _lib.call("msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
+            self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
                       ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, st)
-            _lib.call("msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
+            self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
                       sp["cout"], S, st)
             # z_i = dw(relu(bn(y_{i-1}))): BN1 backward, then depthwise bwd-weight / bwd-data
             self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
-            _lib.call("msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
+            self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
                       ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials), N, sp["cin"], pd, ph,
                       pw, s, st)
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
-            _lib.call("msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
+            self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
                       sp["cin"], pd, ph, pw, s, accumulate, st)
             if on_bucket_ready:
                 on_bucket_ready(i)
@@ -355,7 +378,7 @@ class Engine:
         self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st)
         D, H, W = pl.in_dims
         sd, sh, sw = specs[0]["stride"]
-        _lib.call("msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]),
+        self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]),
                   ptr(pl.ws), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         if on_bucket_ready:
             on_bucket_ready(0)
