@@ -1,0 +1,70 @@
+"""Data-parallel plumbing on CPU (gloo, world_size 2): the bucketed gradient all-reduce of
+mslesions3d_amd/parallel.py over the flat gradient arena — coverage, trigger order, averaging."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_buckets, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mslesions3d_amd.engine import ParamArena
+        from mslesions3d_amd.parallel import GradBucketReducer, broadcast_model
+        from mslesions3d_amd.ssd3d import LSSD3D
+        torch.manual_seed(100 + rank)  # different initial weights per rank on purpose
+        model = LSSD3D(n_classes=2, input_channels=1, input_size=(64, 64, 64), threshold=[0.1, 0.2])
+        arena = ParamArena(model, torch.device("cpu"))
+        model._engine.arena = arena
+        broadcast_model(model, src=0)
+        ref = [torch.zeros_like(arena.flat) for _ in range(world)]
+        dist.all_gather(ref, arena.flat)
+        assert torch.equal(ref[0], ref[1]), "broadcast must make the replicas identical"
+        red = GradBucketReducer(arena, n_buckets=n_buckets)
+        assert red.world == world
+        # buckets tile the gradient arena exactly once
+        assert red.ranges[0][0] == 0 and red.ranges[-1][1] == arena.n_trainable
+        assert all(a[1] == b[0] for a, b in zip(red.ranges, red.ranges[1:]))
+        assert sorted(k for ks in red.trigger.values() for k in ks) == list(range(len(red.ranges)))
+        # fake backward: every parameter's gradient becomes available at its stage
+        g = torch.Generator().manual_seed(7 + rank)
+        local = torch.randn(arena.n_trainable, generator=g)
+        arena.grad.zero_()
+        fired = []
+        for stage in ["heads", 7, 6, 5, 4, 3, 2, 1, 0]:
+            for name in arena.names:
+                if name in arena.no_grad_names:
+                    continue
+                st = "heads" if name.startswith("pred_convs") else int(name.split(".")[2])
+                if st == stage:
+                    lo, n = arena.offsets[name]
+                    arena.grad[lo:lo + n] = local[lo:lo + n]
+            before = len(red.pending)
+            red.on_stage(stage)
+            fired.append(len(red.pending) - before)
+        scale = red.finish()
+        assert scale == 1.0 / world and sum(fired) == len(red.ranges)
+        both = [torch.zeros_like(local) for _ in range(world)]
+        dist.all_gather(both, local)
+        assert torch.allclose(arena.grad, both[0] + both[1], rtol=0, atol=0), "bucketed all-reduce must equal the plain sum"
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_buckets", [1, 3])
+def test_bucketed_allreduce_gloo_world2(tmp_path, n_buckets):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), n_buckets, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
