@@ -65,7 +65,7 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
 
 /* ---- pointwise Conv3d(Cin,Cout,k1) = per-image GEMM on MFMA : Block.conv2, mobilenet.py:40,45 ------------- */
-int msl_pwconv_fwd_num_partials(int N, int S);
+int msl_pwconv_fwd_num_partials(int N, int Cin, int S);
 int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int Cin, int Cout, int S, void* stream);
 int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,

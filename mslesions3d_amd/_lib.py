@@ -31,7 +31,7 @@ _SIGNATURES = {
     "msl_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "msl_pwconv_fwd_num_partials": (_I, [_I, _I]),
+    "msl_pwconv_fwd_num_partials": (_I, [_I, _I, _I]),
     "msl_pwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I]),

@@ -116,6 +116,75 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
   *reinterpret_cast<float4*>(dst) = make_float4(g[0], g[1], g[2], g[3]);
 }
 
+// Stride-2 specialisation: one thread owns the 2 x 2 x 4 input patch (id in {2a, 2a+1}) x (ih in {2b, 2b+1}) x
+// (iw0 .. iw0+3).  The parity of every coordinate is then static: the 16 outputs read the same 12 dy values and
+// every weight index is a compile-time constant (54 FMAs, no tap selection), and the patch is written as four
+// 16-B stores.  This is the kernel that writes the 134 MB stem-gradient tensor.
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* __restrict__ dy,
+                                                                   const float* __restrict__ w,
+                                                                   float* __restrict__ g_in, int C, int D, int H, int W,
+                                                                   int OD, int OH, int OW, int accumulate) {
+  const int nc = blockIdx.y, c = nc % C;
+  const int W4 = W >> 2, H2 = (H + 1) >> 1, D2 = (D + 1) >> 1;
+  const int q = blockIdx.x * 256 + threadIdx.x;
+  if (q >= D2 * H2 * W4) return;
+  const int cw = q % W4, b = (q / W4) % H2, a = q / (W4 * H2);
+  const int iw0 = cw * 4, c2 = cw * 2;
+  float wk[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = w[c * 27 + k];
+  const float* dyc = dy + (size_t)nc * OD * OH * OW;
+  float dv[2][2][3];
+#pragma unroll
+  for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+      for (int ww = 0; ww < 3; ++ww) {
+        const bool ok = a + dd < OD && b + hh < OH && c2 + ww < OW;
+        dv[dd][hh][ww] = ok ? dyc[((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww] : 0.f;
+      }
+  // per axis: even index -> (offset 0, k = 1); odd index -> (offset 1, k = 0) and (offset 0, k = 2)
+  float g[2][2][4];
+#pragma unroll
+  for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+      for (int td = 0; td < (pd ? 2 : 1); ++td) {
+        const int dd = pd ? (td == 0 ? 1 : 0) : 0, kd = pd ? (td == 0 ? 0 : 2) : 1;
+#pragma unroll
+        for (int th = 0; th < (ph ? 2 : 1); ++th) {
+          const int hh = ph ? (th == 0 ? 1 : 0) : 0, kh = ph ? (th == 0 ? 0 : 2) : 1;
+          const float w0 = wk[kd * 9 + kh * 3 + 0], w1 = wk[kd * 9 + kh * 3 + 1], w2 = wk[kd * 9 + kh * 3 + 2];
+          const float d0 = dv[dd][hh][0], d1 = dv[dd][hh][1], d2 = dv[dd][hh][2];
+          o0 = fmaf(w1, d0, o0);
+          o1 = fmaf(w0, d1, fmaf(w2, d0, o1));
+          o2 = fmaf(w1, d1, o2);
+          o3 = fmaf(w0, d2, fmaf(w2, d1, o3));
+        }
+      }
+      g[pd][ph][0] = o0; g[pd][ph][1] = o1; g[pd][ph][2] = o2; g[pd][ph][3] = o3;
+    }
+  float* base = g_in + (size_t)nc * D * H * W;
+#pragma unroll
+  for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int id = 2 * a + pd, ih = 2 * b + ph;
+      if (id < D && ih < H) {
+        float* dst = base + ((size_t)id * H + ih) * W + iw0;
+        float4 v = make_float4(g[pd][ph][0], g[pd][ph][1], g[pd][ph][2], g[pd][ph][3]);
+        if (accumulate) {
+          const float4 old = *reinterpret_cast<const float4*>(dst);
+          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        }
+        *reinterpret_cast<float4*>(dst) = v;
+      }
+    }
+}
+
 // generic fallback: one input voxel per thread, any shape
 __global__ __launch_bounds__(256) void dw_bwd_data_naive_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                                 float* __restrict__ g_in, int C, int D, int H, int W,
@@ -144,25 +213,30 @@ __global__ __launch_bounds__(256) void dw_bwd_data_naive_kernel(const float* __r
   }
 }
 
-// bwd-weight: grid (chunks, C, N); each block reduces `BW_CHUNK` outputs of one (n, c) into 27 fp64 partials
-constexpr int BW_CHUNK = 4096;
+// bwd-weight: one WAVE per work item (n, c, chunk of BW_CHUNK outputs): 27 accumulators per lane, a shuffle
+// reduction at the end, no workgroup barrier at all (the tail layers have only 64 outputs per (n, c)).
+constexpr int BW_CHUNK = 1024;
 __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift,
                                                             double* __restrict__ partials, int C, int D, int H, int W,
-                                                            int OD, int OH, int OW, int stride, int chunks) {
-  __shared__ double scratch[8];
-  const int chunk = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+                                                            int OD, int OH, int OW, int stride, int chunks, int NP,
+                                                            int total_items) {
+  const int lane = threadIdx.x & 63;
+  const int item = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= total_items) return;
+  const int chunk = item % chunks, nc = item / chunks;
+  const int c = nc % C, n = nc / C;
   const int OS = OD * OH * OW;
   const bool affine = in_scale != nullptr;
   const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
-  const float* xc = x + ((size_t)n * C + c) * D * H * W;
-  const float* dyc = dy + ((size_t)n * C + c) * OS;
+  const float* xc = x + (size_t)nc * D * H * W;
+  const float* dyc = dy + (size_t)nc * OS;
   float acc[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) acc[k] = 0.f;
   const int lo = chunk * BW_CHUNK, hi = min(OS, lo + BW_CHUNK);
-  for (int o = lo + threadIdx.x; o < hi; o += 256) {
+  for (int o = lo + lane; o < hi; o += 64) {
     const int ow = o % OW, oh = (o / OW) % OH, od = o / (OW * OH);
     const float d = dyc[o];
 #pragma unroll
@@ -182,12 +256,11 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
       }
     }
   }
-  const int NP = gridDim.z * chunks, p = n * chunks + chunk;
+  const int p = n * chunks + chunk;
 #pragma unroll
   for (int k = 0; k < 27; ++k) {
-    const double t = msl::block_sum((double)acc[k], scratch);
-    if (threadIdx.x == 0) partials[((size_t)c * 27 + k) * NP + p] = t;
-    __syncthreads();
+    const double t = msl::wave_sum((double)acc[k]);
+    if (lane == 0) partials[((size_t)c * 27 + k) * NP + p] = t;
   }
 }
 
@@ -211,9 +284,13 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
   if (W % 4 == 0) {
-    dim3 grid(msl::cdiv(D * H * (W / 4), 256), N * C);
-    if (stride == 2) hipLaunchKernelGGL(dw_bwd_data_kernel<2>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
-    else hipLaunchKernelGGL(dw_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
+    if (stride == 2) {
+      dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
+      hipLaunchKernelGGL(dw_bwd_data_s2_patch_kernel, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
+    } else {
+      dim3 grid(msl::cdiv(D * H * (W / 4), 256), N * C);
+      hipLaunchKernelGGL(dw_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
+    }
   } else {
     dim3 grid(std::min(msl::cdiv(D * H * W, 256), 256), N * C);
     hipLaunchKernelGGL(dw_bwd_data_naive_kernel, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, stride, accumulate);
@@ -234,8 +311,9 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   const int chunks = msl::cdiv(OD * OH * OW, BW_CHUNK);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(chunks, C, N), dim3(256), 0, st, dy, x, in_scale, in_shift, partials,
-                     C, D, H, W, OD, OH, OW, stride, chunks);
+  const int total_items = N * C * chunks;
+  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(msl::cdiv(total_items, 4)), dim3(256), 0, st, dy, x, in_scale, in_shift,
+                     partials, C, D, H, W, OD, OH, OW, stride, chunks, N * chunks, total_items);
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, N * chunks, dw, C * 27);
   MSL_LAUNCH_CHECK();

@@ -126,6 +126,154 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
+// K-split variant for K >= 128 (blocks 3-7 forward, blocks 2-7 bwd-data): the GEMMs of the tail layers are tiny
+// (down to 512 x 64 x 512 per image), so a 64 x 128 tile with a serial K loop leaves the chip idle behind load
+// latency.  Here a workgroup owns a 32 x 64 tile and its 4 waves each take a quarter of K (private LDS
+// staging, next chunk prefetched into registers during the MFMAs), followed by a fixed-order reduction.
+constexpr int KS_BM = 32, KS_BN = 64;
+constexpr int KS_WAVE_LDS = BK * KS_BN + KS_BM * WS_LD;  // floats per wave
+
+template <bool AFFINE, bool STATS, bool TRANS_W>
+__global__ __launch_bounds__(256) void pw_gemm_ksplit_kernel(const float* __restrict__ X,
+                                                             const float* __restrict__ in_scale,
+                                                             const float* __restrict__ in_shift,
+                                                             const float* __restrict__ Wt, float* __restrict__ Y,
+                                                             double* __restrict__ partials, int M, int K, int S) {
+  __shared__ __align__(16) float lds[4 * KS_WAVE_LDS];
+  const int n = blockIdx.z, m0 = blockIdx.y * KS_BM, s0 = blockIdx.x * KS_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  float* Xs = lds + wv * KS_WAVE_LDS;   // [BK][KS_BN]
+  float* Ws = Xs + BK * KS_BN;          // [KS_BM][WS_LD]
+  const float* Xn = X + (size_t)n * K * S;
+  const bool vec_ok = (S & 3) == 0;
+  const int kq = K >> 2;                // K range of this wave
+  const int kbeg = wv * kq;
+  const int nchunks = kq / BK;
+
+  float4 xr[8], wr[4];
+  auto load_chunk = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = (lane >> 4) + i * 4, c4 = (lane & 15) * 4, col = s0 + c4;
+      const float* src = Xn + (size_t)(k0 + r) * S + col;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (vec_ok && col + 3 < S) {
+        v = *reinterpret_cast<const float4*>(src);
+      } else {
+        if (col < S) v.x = src[0];
+        if (col + 1 < S) v.y = src[1];
+        if (col + 2 < S) v.z = src[2];
+        if (col + 3 < S) v.w = src[3];
+      }
+      if (AFFINE) {
+        const float sc = in_scale[k0 + r], sh = in_shift[k0 + r];
+        v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
+        v.y = col + 1 < S ? msl::act(v.y, sc, sh) : 0.f;
+        v.z = col + 2 < S ? msl::act(v.z, sc, sh) : 0.f;
+        v.w = col + 3 < S ? msl::act(v.w, sc, sh) : 0.f;
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!TRANS_W) {
+        const int m = (lane >> 3) + i * 8, k4 = (lane & 7) * 4;
+        if (m0 + m < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(m0 + m) * K + k0 + k4);
+      } else {
+        const int k = (lane >> 3) + i * 8, m4 = (lane & 7) * 4;
+        if (m0 + m4 + 3 < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + k) * M + m0 + m4);
+      }
+      wr[i] = v;
+    }
+  };
+  auto store_chunk = [&]() {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int r = (lane >> 4) + i * 4, c4 = (lane & 15) * 4;
+      *reinterpret_cast<float4*>(Xs + r * KS_BN + c4) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!TRANS_W) {
+        const int m = (lane >> 3) + i * 8, k4 = (lane & 7) * 4;
+        float* d = Ws + m * WS_LD + k4;
+        d[0] = wr[i].x; d[1] = wr[i].y; d[2] = wr[i].z; d[3] = wr[i].w;
+      } else {
+        const int k = (lane >> 3) + i * 8, m4 = (lane & 7) * 4;
+        Ws[(m4 + 0) * WS_LD + k] = wr[i].x; Ws[(m4 + 1) * WS_LD + k] = wr[i].y;
+        Ws[(m4 + 2) * WS_LD + k] = wr[i].z; Ws[(m4 + 3) * WS_LD + k] = wr[i].w;
+      }
+    }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  load_chunk(kbeg);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();  // the previous chunk has been consumed
+    store_chunk();
+    __syncthreads();
+    if (ch + 1 < nchunks) load_chunk(kbeg + (ch + 1) * BK);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) {
+      const int kr = 2 * kk + (lane >> 5);
+      const float a = Ws[(lane & 31) * WS_LD + kr];
+      const float b0 = Xs[kr * KS_BN + (lane & 31)];
+      const float b1 = Xs[kr * KS_BN + 32 + (lane & 31)];
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
+    }
+  }
+  // fixed-order reduction over the 4 K-quarters: 3, 2, 1 into LDS, wave 0 adds its own and finishes
+  __syncthreads();
+  float* red = lds;  // [32][64 + 1]
+  constexpr int RLD = KS_BN + 1;
+  for (int w2 = 3; w2 >= 1; --w2) {
+    if (wv == w2) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        float* p0 = red + row * RLD + (lane & 31);
+        if (w2 == 3) {
+          p0[0] = acc0[r];
+          p0[32] = acc1[r];
+        } else {
+          p0[0] += acc0[r];
+          p0[32] += acc1[r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (wv != 0) return;
+  float* Yn = Y + (size_t)n * M * S;
+  const int colbase = s0 + (lane & 31);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    const int row = m0 + rl;
+    const float v0 = acc0[r] + red[rl * RLD + (lane & 31)];
+    const float v1 = acc1[r] + red[rl * RLD + 32 + (lane & 31)];
+    if (row < M && colbase < S) Yn[(size_t)row * S + colbase] = v0;
+    if (row < M && colbase + 32 < S) Yn[(size_t)row * S + colbase + 32] = v1;
+    if (STATS) {
+      float s = v0 + v1;
+      float q = fmaf(v0, v0, v1 * v1);
+#pragma unroll
+      for (int m = 16; m > 0; m >>= 1) {
+        s += __shfl_xor(s, m, 64);
+        q += __shfl_xor(q, m, 64);
+      }
+      if ((lane & 31) == 0 && row < M && partials) {
+        const int NP = gridDim.z * gridDim.x, p = n * gridDim.x + blockIdx.x;
+        partials[(size_t)row * NP + p] = (double)s;
+        partials[((size_t)M + row) * NP + p] = (double)q;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // bwd-weight.  Block = (k-split, output tile 64 x BNN).  The 4 waves split every 64-position chunk four
 // ways and each keeps the whole tile's accumulators; fixed-order in-block reduction, then one slab per block.
 constexpr int PC = 64, PC_LD = PC + 1;
@@ -265,14 +413,28 @@ BwPlan bw_plan(int N, int Cin, int Cout, int S) {
 
 extern "C" {
 
-int msl_pwconv_fwd_num_partials(int N, int S) { return N * msl::cdiv(S, BN); }
+static inline bool use_ksplit(int K) { return K >= 128 && K % 128 == 0; }
+
+int msl_pwconv_fwd_num_partials(int N, int Cin, int S) { return N * msl::cdiv(S, use_ksplit(Cin) ? KS_BN : BN); }
 
 // z (N,Cin,S) raw + input affine -> y (N,Cout,S) raw + stat partials [2][Cout][NP]
 int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int Cin, int Cout, int S, void* stream) {
   if (N <= 0 || S <= 0 || Cin % BK != 0 || Cout % 4 != 0) return MSL_ERR_ARG;
-  dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cout, BM), N);
   hipStream_t st = (hipStream_t)stream;
+  if (use_ksplit(Cin)) {
+    dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cout, KS_BM), N);
+    if (in_scale) {
+      if (partials) hipLaunchKernelGGL((pw_gemm_ksplit_kernel<true, true, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+      else hipLaunchKernelGGL((pw_gemm_ksplit_kernel<true, false, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+    } else {
+      if (partials) hipLaunchKernelGGL((pw_gemm_ksplit_kernel<false, true, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+      else hipLaunchKernelGGL((pw_gemm_ksplit_kernel<false, false, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+    }
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
+  dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cout, BM), N);
   if (in_scale) {
     if (partials) hipLaunchKernelGGL((pw_gemm_kernel<true, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
     else hipLaunchKernelGGL((pw_gemm_kernel<true, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
@@ -288,6 +450,13 @@ int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift,
 int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,
                         void* stream) {
   if (N <= 0 || S <= 0 || Cout % BK != 0 || Cin % 4 != 0) return MSL_ERR_ARG;
+  if (use_ksplit(Cout)) {
+    dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cin, KS_BM), N);
+    hipLaunchKernelGGL((pw_gemm_ksplit_kernel<false, false, true>), g2, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
+                       nullptr, w, g_in, nullptr, Cin, Cout, S);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
   dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cin, BM), N);
   hipLaunchKernelGGL((pw_gemm_kernel<false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
                      nullptr, w, g_in, nullptr, Cin, Cout, S);

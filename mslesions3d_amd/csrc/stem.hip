@@ -151,16 +151,18 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     const int ow0 = seg * 64;
     const int npos = live ? min(64, OW - ow0) : 0;
     __syncthreads();  // previous chunk's LDS reads are done
-    // dy tile: lane = position
+    // Issue every global load of the chunk first (32 dy + 9*CIN*3 input values per lane in flight), then
+    // store to LDS: a load->store->load chain would expose the full memory latency 59 times per chunk.
+    float dreg[32];
     {
       const float* src = dy + (size_t)n * 32 * OS + ((size_t)od * OH + oh) * OW + ow0 + lane;
-#pragma unroll 8
-      for (int co = 0; co < 32; ++co) dyt[co * SB_DY_LD + lane] = lane < npos ? src[(size_t)co * OS] : 0.f;
+#pragma unroll
+      for (int co = 0; co < 32; ++co) dreg[co] = lane < npos ? src[(size_t)co * OS] : 0.f;
     }
-    // input rows: iw = ow0*sw - 1 + j, j in [0, 64*sw + 1]
+    float xreg[CIN * 9][3];
     {
       const int iw0 = ow0 * sw - 1;
-      const int span = 64 * sw + 1;
+      const int span = 64 * sw + 1;  // j in [0, span]
 #pragma unroll
       for (int ci = 0; ci < CIN; ++ci)
 #pragma unroll
@@ -168,12 +170,22 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
           const int id = od * sd - 1 + rr / 3, ih = oh * sh - 1 + rr % 3;
           const bool rok = live && id >= 0 && id < D && ih >= 0 && ih < H;
           const float* src = x + (((size_t)n * CIN + ci) * D + (rok ? id : 0)) * H * W + (size_t)(rok ? ih : 0) * W;
-          for (int j = lane; j <= span; j += 64) {
-            const int iw = iw0 + j;
-            rows[(ci * 9 + rr) * SB_ROW_LD + j] = (rok && iw >= 0 && iw < W) ? src[iw] : 0.f;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int j = lane + 64 * t, iw = iw0 + j;
+            xreg[ci * 9 + rr][t] = (rok && j <= span && iw >= 0 && iw < W) ? src[iw] : 0.f;
           }
         }
     }
+#pragma unroll
+    for (int co = 0; co < 32; ++co) dyt[co * SB_DY_LD + lane] = dreg[co];
+#pragma unroll
+    for (int r2 = 0; r2 < CIN * 9; ++r2)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int j = lane + 64 * t;
+        if (j < SB_ROW_LD) rows[r2 * SB_ROW_LD + j] = xreg[r2][t];
+      }
     __syncthreads();
 #pragma unroll 4
     for (int s = 0; s < 32; ++s) {

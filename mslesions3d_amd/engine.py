@@ -123,7 +123,7 @@ class Plan:
                 self.bn_z.append(torch.zeros((BN_ROWS, sp["cin"]), **f32))
                 part_elems = max(part_elems,
                                  2 * sp["cin"] * L.msl_dwconv_fwd_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]),
-                                 2 * sp["cout"] * L.msl_pwconv_fwd_num_partials(N, S))
+                                 2 * sp["cout"] * L.msl_pwconv_fwd_num_partials(N, sp["cin"], S))
                 if need_grad:
                     part_elems = max(part_elems,
                                      sp["cin"] * 27 * L.msl_dwconv_bwd_weight_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]),
@@ -281,7 +281,7 @@ class Engine:
                          N * S, training, st)
             self._k(f"pw_fwd{i}", "msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(blk.conv2.weight),
                       ptr(pl.y[i]), pp, N, sp["cin"], sp["cout"], S, st)
-            self._bn_fwd(blk.bn2, pl.bn_y[i], part, L.msl_pwconv_fwd_num_partials(N, S), N * S, training, st)
+            self._bn_fwd(blk.bn2, pl.bn_y[i], part, L.msl_pwconv_fwd_num_partials(N, sp["cin"], S), N * S, training, st)
             if i in pl.fpad:
                 plain = None
                 if want_features:

@@ -160,7 +160,7 @@ def test_pw_fwd_bwd(N, Cin, Cout, S):
     a = torch.relu(z * sc.view(1, -1, 1) + sh.view(1, -1, 1)).requires_grad_(True)
     ref = torch.einsum("oc,ncs->nos", w, a)
     y = torch.full(ref.shape, float("nan"), device=DEV)
-    NP = L.msl_pwconv_fwd_num_partials(N, S)
+    NP = L.msl_pwconv_fwd_num_partials(N, Cin, S)
     part = torch.zeros(2 * Cout * NP, dtype=torch.float64, device=DEV)
     _lib.call("msl_pwconv_fwd", ptr(K(z)), ptr(K(sc)), ptr(K(sh)), ptr(K(w.detach())), ptr(y), ptr(part),
               N, Cin, Cout, S, st())
