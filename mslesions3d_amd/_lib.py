@@ -54,6 +54,7 @@ _SIGNATURES = {
     "msl_detect_objects": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I] + [_P] * 14 + [_P]),
     "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "msl_nan_flag": (_I, [_P, _Z, _P, _I, _P]),
+    "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
 }
 
 _lib = None
@@ -96,6 +97,52 @@ def check(code, what):
                              f"({'bad argument' if code == -1 else 'unsupported shape' if code == -2 else 'hipError'})")
 
 
-def call(name, *args):
+# -- launch programs ------------------------------------------------------------------------------------------
+# A training step is a fixed sequence of ~140 launches whose arguments (device pointers, sizes, stream) do not
+# change from step to step.  While a recorder is active every `call` is also appended to it; `replay` then
+# re-issues the sequence with no Python between two launches except the ctypes call itself.
+_recorder = None
+
+
+def start_recording():
+    global _recorder
+    _recorder = []
+
+
+def stop_recording():
+    global _recorder
+    prog, _recorder = _recorder, None
+    return prog
+
+
+def record_hook(fn, tag=None):
+    """Insert a Python callback (e.g. 'start the all-reduce of bucket k') into the program being recorded."""
+    if _recorder is not None:
+        _recorder.append((None, fn, tag))
+
+
+def call(name, *args, tag=None):
     """Invoke an int-returning entry point and raise on a non-zero code."""
-    check(getattr(load(), name)(*args), name)
+    fn = getattr(load(), name)
+    if _recorder is not None:
+        _recorder.append((fn, args, tag or name))
+    check(fn(*args), name)
+
+
+def replay(prog, timed_tags=None, sink=None, event_factory=None):
+    """Re-issue a recorded program.  ``timed_tags``/``sink``: record an event pair around the tagged launches."""
+    for fn, args, tag in prog:
+        if fn is None:
+            args()
+        elif timed_tags is not None and tag in timed_tags:
+            e0, e1 = event_factory(), event_factory()
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            sink.setdefault(tag, []).append((e0, e1))
+            if rc:
+                check(rc, tag)
+        else:
+            rc = fn(*args)
+            if rc:
+                check(rc, tag)

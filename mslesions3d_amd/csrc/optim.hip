@@ -59,6 +59,13 @@ int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream) {
   return MSL_OK;
 }
 
+// 32-bit fill on the stream (replaces torch's .zero_() inside recorded launch programs)
+int msl_fill_u32(void* dst, unsigned int value, size_t count, void* stream) {
+  if (count == 0) return MSL_OK;
+  hipError_t e = hipMemsetD32Async((hipDeviceptr_t)dst, (int)value, count, (hipStream_t)stream);
+  return e == hipSuccess ? MSL_OK : (int)e;
+}
+
 int msl_abi_version(void) { return 1; }
 
 }  // extern "C"

@@ -210,6 +210,10 @@ class Engine:
         """Record a HIP event pair (on the launch stream) around every tagged launch; tags=None -> all."""
         self.prof, self.prof_tags = {}, (None if tags is None else set(tags))
 
+    def prof_all(self):
+        """True while every launch is being timed (the trainer then uses the eager path, which tags every launch)."""
+        return self.prof is not None and self.prof_tags is None
+
     def stop_profile(self):
         """-> {tag: [ms, ...]} (synchronises)."""
         torch.cuda.synchronize()
@@ -219,13 +223,19 @@ class Engine:
 
     def _k(self, tag, name, *args):
         if self.prof is None or (self.prof_tags is not None and tag not in self.prof_tags):
-            _lib.call(name, *args)
+            _lib.call(name, *args, tag=tag)
             return
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        _lib.call(name, *args)
+        _lib.call(name, *args, tag=tag)
         e1.record()
         self.prof.setdefault(tag, []).append((e0, e1))
+
+    @staticmethod
+    def _hook(cb, tag):
+        if cb is not None:
+            cb(tag)
+            _lib.record_hook(lambda: cb(tag), tag=f"hook:{tag}")
 
     def _bn_fwd(self, bn, vec, partials, NP, count, training, st):
         C = vec.shape[1]
@@ -258,7 +268,7 @@ class Engine:
         specs = self.layer_specs
         part = pl.partials
         pp = ptr(part) if training else None
-        pl.nan_flag.zero_()
+        _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
 
         # stem (features[0] = Conv3d + BN + ReLU)
         D, H, W = pl.in_dims
@@ -344,8 +354,7 @@ class Engine:
                       ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
                       ptr(pl.head_ws[f]), N, C, D, H, W, ncls, st)
             self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W, ncls, st)
-        if on_bucket_ready:
-            on_bucket_ready("heads")
+        self._hook(on_bucket_ready, "heads")
         last = len(specs) - 1
         for i in range(last, 0, -1):
             sp = specs[i]
@@ -370,8 +379,7 @@ class Engine:
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
             self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
                       sp["cin"], pd, ph, pw, s, accumulate, st)
-            if on_bucket_ready:
-                on_bucket_ready(i)
+            self._hook(on_bucket_ready, i)
         # stem
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
@@ -380,8 +388,7 @@ class Engine:
         sd, sh, sw = specs[0]["stride"]
         self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]),
                   ptr(pl.ws), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
-        if on_bucket_ready:
-            on_bucket_ready(0)
+        self._hook(on_bucket_ready, 0)
 
     def check_nan(self, pl):
         """One host sync: raise like ssd3d.py:258-261 if the forward produced NaN."""

@@ -56,10 +56,16 @@ class FusedAdam:
                     view.zero_()
                 elif g.data_ptr() != view.data_ptr():
                     view.copy_(g)
-        self.step_count += 1
-        self.hp.copy_(torch.tensor(self.hyper(grad_scale), dtype=torch.float32), non_blocking=True)
+        self.prepare_step(grad_scale)
         _lib.call("msl_adam_step", ptr(arena.flat), ptr(arena.grad), ptr(self.exp_avg), ptr(self.exp_avg_sq), ptr(self.hp),
                   ptr(arena.is_bias), arena.n_trainable, torch.cuda.current_stream().cuda_stream)
+
+    def prepare_step(self, grad_scale=1.0):
+        """Host side of a step: advance the step counter and refresh the 8 hyper-parameter floats the kernel reads
+        (the launch itself may then come from a recorded program)."""
+        self._ensure()
+        self.step_count += 1
+        self.hp.copy_(torch.tensor(self.hyper(grad_scale), dtype=torch.float32), non_blocking=True)
 
     def state_dict(self):
         return {"step": self.step_count, "param_groups": [dict(g) for g in self.param_groups],

@@ -584,7 +584,7 @@ class MultiBoxLoss(nn.Module):
             f32, i32, i64 = torch.float32, torch.int32, torch.int64
             L = _lib.load()
             st = dict(overlap=torch.zeros((N, P), dtype=f32, device=dev), obj=torch.zeros((N, P), dtype=i32, device=dev),
-                      prior_for_obj=torch.zeros(256, dtype=i32, device=dev),
+                      prior_for_obj=torch.zeros(4096, dtype=i32, device=dev),
                       true_classes=torch.zeros((N, P), dtype=i64, device=dev),
                       true_locs=torch.zeros((N, P, 6), dtype=f32, device=dev),
                       matched=torch.zeros((N, P), dtype=i64, device=dev),

@@ -24,27 +24,20 @@ class FusedTrainer:
         self.n_buckets, self.group = n_buckets, process_group
         self.reducer = None
         self.last_plan = None
+        self.use_programs = True
+        self._programs = {}
 
     def _reducer(self, arena):
         if self.reducer is None or self.reducer.arena is not arena:
             self.reducer = GradBucketReducer(arena, self.n_buckets, self.group)
         return self.reducer
 
-    def step_packed(self, images, gt_boxes, gt_labels, obj_off, total_objects, sync=True):
-        """One optimisation step on already packed targets (see MultiBoxLoss.pack_targets).  With ``sync=False``
-        nothing is read back: the returned dict holds the device tensor ``loss_out`` = [conf, loc, n_positives]."""
-        m = self.model
-        if not images.is_cuda:
-            raise _lib.HipKernelError("FusedTrainer runs on the HIP device only (no CPU fallback)")
+    def _eager_step(self, images, gt_boxes, gt_labels, obj_off, total_objects, red):
+        """Issue every launch of one step through the Python executor (and record it if a recorder is active)."""
+        m, eng, lf = self.model, self.model._engine, self.model.loss_fn
         dev = images.device
-        m._ensure_device_state(dev)
-        eng = m._engine
-        arena = eng.ensure_arena(dev)
-        red = self._reducer(arena)
         locs, scores = eng.forward(images, training=True, need_grad=True)
         pl = eng.plan_for(images, True)
-        self.last_plan = pl
-        lf = m.loss_fn
         N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
         st = lf._state(N, P, ncls, total_objects, dev)
         lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects)
@@ -56,7 +49,49 @@ class FusedTrainer:
                   torch.cuda.current_stream().cuda_stream)
         eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red.on_stage)
         scale = red.finish()
+        _lib.record_hook(red.finish, tag="hook:finish")
         self.opt.step(grad_scale=scale, gather_autograd_grads=False)
+        return pl, st
+
+    def step_packed(self, images, gt_boxes, gt_labels, obj_off, total_objects, sync=True):
+        """One optimisation step on already packed targets (see MultiBoxLoss.pack_targets).  With ``sync=False``
+        nothing is read back: the returned dict holds the device tensor ``loss_out`` = [conf, loc, n_positives].
+
+        The first step on a given set of buffers runs through the Python executor and records its ~140 launches;
+        later steps replay that launch program (same kernels, same arguments, no Python in between)."""
+        m = self.model
+        if not images.is_cuda:
+            raise _lib.HipKernelError("FusedTrainer runs on the HIP device only (no CPU fallback)")
+        dev = images.device
+        m._ensure_device_state(dev)
+        eng = m._engine
+        arena = eng.ensure_arena(dev)
+        red = self._reducer(arena)
+        stream = torch.cuda.current_stream().cuda_stream
+        st0 = m.loss_fn._state(images.shape[0], m.priors_cxcycz.shape[0], m.n_classes, total_objects, dev)
+        key = (st0["prior_for_obj"].data_ptr(), images.data_ptr(), tuple(images.shape), gt_boxes.data_ptr(), gt_labels.data_ptr(), obj_off.data_ptr(),
+               total_objects, stream, id(arena), float(m.loss_fn.alpha))
+        entry = self._programs.get(key) if self.use_programs else None
+        if entry is None or eng.prof_all():
+            if self.use_programs:
+                _lib.start_recording()
+            try:
+                pl, st = self._eager_step(images, gt_boxes, gt_labels, obj_off, total_objects, red)
+            finally:
+                prog = _lib.stop_recording() if self.use_programs else None
+            if self.use_programs:
+                # keep the tensors the program points at alive for as long as the program exists
+                self._programs[key] = (prog, pl, st, (images, gt_boxes, gt_labels, obj_off))
+        else:
+            prog, pl, st, _ = entry
+            pl.generation += 1
+            pl.saved_input, pl.trained_mode = images, True
+            self.opt.prepare_step(grad_scale=1.0 / red.world)
+            if eng.prof is not None:
+                _lib.replay(prog, eng.prof_tags, eng.prof, lambda: torch.cuda.Event(enable_timing=True))
+            else:
+                _lib.replay(prog)
+        self.last_plan = pl
         if self.sch is not None:
             self.sch.step()
         m.global_step += 1
@@ -66,7 +101,7 @@ class FusedTrainer:
             conf, loc, npos = st["loss_out"].tolist()
             if loc != loc:  # ssd3d.py:938-940
                 raise Exception("Loss is NaN")
-            out.update(conf=conf, loc=loc, loss=conf + float(lf.alpha) * loc, n_positives=int(npos))
+            out.update(conf=conf, loc=loc, loss=conf + float(m.loss_fn.alpha) * loc, n_positives=int(npos))
         return out
 
     def step(self, images, boxes, labels, sync=True):

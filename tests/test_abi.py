@@ -27,7 +27,7 @@ def _ctype_of(param):
     if "*" in param:
         return ctypes.c_void_p
     base = param.rsplit(" ", 1)[0].replace("const ", "").strip()
-    return {"int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
+    return {"int": ctypes.c_int, "unsigned int": ctypes.c_uint, "float": ctypes.c_float, "double": ctypes.c_double, "size_t": ctypes.c_size_t,
             "long long": ctypes.c_longlong}[base]
 
 

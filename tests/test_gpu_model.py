@@ -216,6 +216,31 @@ def test_fused_step_equals_autograd_step():
         assert torch.equal(pa, pb), f"{k} differs between the autograd and the fused step"
 
 
+def test_replayed_launch_program_equals_eager_steps():
+    """Steps 2..n of FusedTrainer replay a recorded launch program; they must equal the Python-driven steps."""
+    from mslesions3d_amd.ssd3d import MultiBoxLoss
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (64, 64, 64), 2
+    batches = []
+    for k in range(2):
+        xs = detinit.make_volume_batch(50 + k, n, 1, size).to(DEV)
+        bs, ls = detinit.make_gt(60 + k, n, size)
+        batches.append((xs,) + MultiBoxLoss.pack_targets(bs, ls, torch.device(DEV)))
+    results = []
+    for use_programs in (True, False):
+        m = hip_model(1, size, lr=1e-3)
+        m.train()
+        tr = FusedTrainer(m)
+        tr.use_programs = use_programs
+        losses = [tr.step_packed(*batches[s % 2])["loss"] for s in range(6)]
+        if use_programs:
+            assert len(tr._programs) == 2
+        results.append((losses, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(),
+                        m.state_dict()["base.features.3.bn2.running_var"].clone()))
+    assert results[0][0] == results[1][0]
+    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+
+
 def test_determinism_run_to_run():
     size, n = (64, 64, 64), 2
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
