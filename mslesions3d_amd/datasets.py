@@ -1,0 +1,143 @@
+"""MONAI-free synthetic data path — host-side mirror of the parts of the reference's
+``lesions3d/datasets.py:50-95,359-485`` and ``generate_artificial_dataset.py`` that the example pipeline uses.
+
+Same directory layout (``<root>/multiple_objects/one_class/<name>/{images,labels}/sub-XXXX_{image,seg}.*``), same
+80/20 split (``train_test_split(random_state=970205)``), same per-sample pipeline (add channel ->
+NormalizeIntensity(nonzero=True) -> boxes from connected components of the mask, ``utils.py:450-513``) and the same
+batch dict from ``collate_fn`` (``datasets.py:86-94``).  Files are ``.npy`` because nibabel is not installed here
+(``.nii.gz`` is read when nibabel is importable).  This is data plumbing in front of the hot path, on the host, as in
+the reference; MONAI's exact NormalizeIntensity arithmetic is not pinned (MONAI absent) — population mean/std over
+the non-zero voxels is used.
+"""
+import os
+from os.path import join as pjoin
+
+import numpy as np
+import torch
+from scipy.ndimage import label as cc_label
+from torch.utils.data import DataLoader, Dataset
+
+from .synth import make_case
+
+
+def generate_artificial_dataset(output_dir, dataset_name, num_images=20, image_size=(64, 64, 64), num_objects=(1, 5),
+                                object_size=(6, 14), random_seed=0):
+    """generate_artificial_dataset.py:63-111 (n_classes = 1, noise on), one file pair per case."""
+    root = pjoin(output_dir, "multiple_objects", "one_class", dataset_name)
+    os.makedirs(pjoin(root, "images"), exist_ok=True)
+    os.makedirs(pjoin(root, "labels"), exist_ok=True)
+    for idx in range(num_images):
+        np.random.seed(random_seed + idx)
+        data = np.random.rand(*image_size)
+        mask = np.zeros(image_size)
+        n = np.random.randint(*num_objects)
+        for _ in range(n + 1):
+            size = np.random.randint(object_size[0], object_size[1])
+            np.random.randint(0, 1)
+            tl = [np.random.randint(0, image_size[i] - size) for i in range(3)]
+            sl = tuple(slice(t, t + size) for t in tl)
+            data[sl] = data[sl] + 0.4
+            data = data.clip(0, 1)
+            mask[sl] = 1
+        np.save(pjoin(root, "images", f"sub-{str(idx).zfill(4)}_image.npy"), data.astype(np.float32))
+        np.save(pjoin(root, "labels", f"sub-{str(idx).zfill(4)}_seg.npy"), mask.astype(np.uint8))
+    return root
+
+
+def boxes_from_segmentation(seg, n_classes=1):
+    """BoundingBoxesGeneratord, 'classes' mode (utils.py:450-513): per class, connected components -> inclusive
+    [min, max] voxel index per axis / image size; zero-volume boxes dropped."""
+    seg = np.squeeze(seg)
+    size = np.array(seg.shape * 2, dtype=np.float32)
+    boxes, labels = [], []
+    for c in range(1, n_classes + 1):
+        comp, n = cc_label(seg == c)
+        for k in range(1, n + 1):
+            idx = np.where(comp == k)
+            b = [idx[0].min(), idx[1].min(), idx[2].min(), idx[0].max(), idx[1].max(), idx[2].max()]
+            boxes.append(b)
+            labels.append(c)
+    boxes = torch.from_numpy(np.asarray(boxes, dtype=np.float32).reshape(-1, 6) / size)
+    labels = torch.tensor(labels, dtype=torch.long)
+    if boxes.numel():
+        keep = ((boxes[:, 3] - boxes[:, 0]) * (boxes[:, 4] - boxes[:, 1]) * (boxes[:, 5] - boxes[:, 2])) != 0
+        boxes, labels = boxes[keep], labels[keep]
+    return boxes, labels
+
+
+def _load(path_noext):
+    if os.path.exists(path_noext + ".npy"):
+        return np.load(path_noext + ".npy")
+    import nibabel as nib  # only when .nii.gz data is supplied
+    return np.asarray(nib.load(path_noext + ".nii.gz").dataobj)
+
+
+class _Cases(Dataset):
+    def __init__(self, root, subjects, n_classes):
+        self.root, self.subjects, self.n_classes = root, subjects, n_classes
+
+    def __len__(self):
+        return len(self.subjects)
+
+    def __getitem__(self, i):
+        s = self.subjects[i]
+        img = _load(pjoin(self.root, "images", f"sub-{s}_image")).astype(np.float32)
+        seg = _load(pjoin(self.root, "labels", f"sub-{s}_seg"))
+        nz = img != 0
+        if nz.any():
+            std = img[nz].std()
+            img[nz] = (img[nz] - img[nz].mean()) / (std if std != 0 else 1.0)
+        boxes, labels = boxes_from_segmentation(seg, self.n_classes)
+        return {"img": torch.from_numpy(img[None]), "boxes": boxes, "labels": labels, "seg": [boxes, labels], "subject": s,
+                "img_meta_dict": {"affine": np.eye(4)}, "seg_meta_dict": {}, "img_transforms": [], "seg_transforms": []}
+
+
+def collate_fn(batch):
+    """datasets.py:50-95: images stacked, ragged boxes / labels kept as lists."""
+    boxes = [b["boxes"] for b in batch]
+    labels = [b["labels"] for b in batch]
+    return {"img": torch.stack([b["img"] for b in batch], 0), "seg": [boxes, labels], "boxes": boxes, "labels": labels,
+            "subject": [b["subject"] for b in batch], "img_meta_dict": [b["img_meta_dict"] for b in batch],
+            "seg_meta_dict": [b["seg_meta_dict"] for b in batch], "img_transforms": [b["img_transforms"] for b in batch],
+            "seg_transforms": [b["seg_transforms"] for b in batch]}
+
+
+class ExampleDataset:
+    """datasets.py:359-485 surface: ``setup(stage)``, ``train_dataloader()``, ``test_dataloader()``,
+    ``predict_dataloader()``, ``train_dataset`` / ``test_dataset``."""
+
+    def __init__(self, n_classes=1, objects="multiple", percentage=1., augmentations=None, batch_size=8, num_workers=0,
+                 verbose=False, random_state=970205, cache=False, subject=None,
+                 data_dir="../data/artificial_dataset", dataset_name=None):
+        assert n_classes == 1 or n_classes == 2
+        d = data_dir + "/multiple_objects" if objects == "multiple" else data_dir
+        d = pjoin(d, "one_class") if n_classes == 1 else pjoin(d, "double_class")
+        self.data_dir = d if dataset_name is None else pjoin(d, dataset_name)
+        self.batch_size, self.num_workers, self.random_state = batch_size, num_workers, random_state
+        self.n_classes, self.subject, self.percentage = n_classes, subject, percentage
+        subs = sorted(s.replace("sub-", "")[:4] for s in os.listdir(pjoin(self.data_dir, "images")) if "sub-" in s)
+        self.subjects_list = subs[:int(percentage * len(subs))] if percentage > 0 else subs
+        self.train_dataset = self.test_dataset = self.predict_dataset = None
+
+    def setup(self, stage=None):
+        from sklearn.model_selection import train_test_split
+        if self.subject is not None:
+            train, test = [self.subject], [self.subject]
+        else:
+            train, test = train_test_split(self.subjects_list, test_size=0.2, random_state=self.random_state)
+        self.train_dataset = _Cases(self.data_dir, train, self.n_classes)
+        self.test_dataset = _Cases(self.data_dir, test, self.n_classes)
+        self.predict_dataset = _Cases(self.data_dir, train if stage == "predict_train" else test, self.n_classes)
+
+    def _loader(self, ds, shuffle, bs=None):
+        return DataLoader(ds, batch_size=bs or self.batch_size, shuffle=shuffle, num_workers=self.num_workers,
+                          collate_fn=collate_fn, drop_last=False)
+
+    def train_dataloader(self):
+        return self._loader(self.train_dataset, True)
+
+    def test_dataloader(self):
+        return self._loader(self.test_dataset, False)
+
+    def predict_dataloader(self):
+        return self._loader(self.predict_dataset, False, 1)

@@ -338,3 +338,33 @@ def test_training_validation_predict_steps():
     assert "val_loss" in v and "metrics_50" in v["log"]
     p = m.predict_step(batch, 0)
     assert len(p) == 3 and len(p[0]) == n and p[0][0].shape[1] == 6
+
+
+def test_train_and_predict_entry_points(tmp_path):
+    """BASELINE configs[0] as plumbing: generated 64^3 volumes, batch 2, 2 epochs of train.py, then predict.py."""
+    import glob
+    import json
+    from mslesions3d_amd import datasets as DS
+    from mslesions3d_amd import predict as P
+    from mslesions3d_amd import train as T
+    DS.generate_artificial_dataset(str(tmp_path / "data"), "toy64", num_images=10, image_size=(64, 64, 64))
+    args = T.build_parser().parse_args(["-d", str(tmp_path / "data"), "-dn", "toy64", "-b", "2", "-me", "2", "-ld",
+                                        str(tmp_path / "logs"), "-en", "run"])
+    model = T.example(args)
+    assert model.global_step == 8  # 8 training cases / batch 2 x 2 epochs
+    lines = [json.loads(l) for l in open(tmp_path / "logs" / "run" / "metrics.jsonl")]
+    assert any("total_loss/training" in l for l in lines) and any("mAP/validation_IoU_0.5" in l for l in lines)
+    ckpts = sorted(glob.glob(str(tmp_path / "logs" / "run" / "*.ckpt")))
+    assert 1 <= len(ckpts) <= 3
+    pargs = P.build_parser().parse_args(["-d", str(tmp_path / "data"), "-dn", "toy64", "-m", ckpts[0], "-o",
+                                         str(tmp_path / "pred"), "-ps", "test", "-sc", "0.3"])
+    metrics = P.predict_example(pargs)
+    assert set(metrics) == {"0.5", "0.1"} and len(metrics["0.5"]) == 2
+    js = sorted(glob.glob(str(tmp_path / "pred" / "sub-*_preds.json")))
+    assert len(js) == 2
+    for v in json.load(open(js[0])).values():
+        assert len(v) == 4 and len(v[0]) == 6 and len(v[1]) == 6
+    # a reloaded checkpoint reproduces the trained model's state dict keys and values
+    from mslesions3d_amd.ssd3d import LSSD3D
+    re = LSSD3D.load_from_checkpoint(ckpts[-1])
+    assert list(re.state_dict().keys()) == list(model.state_dict().keys())
