@@ -45,6 +45,11 @@ int msl_bn_relu_bwd_apply(const float* g, const float* y, const float* scale, co
                           const float* mean, const float* invstd, const float* c1, const float* c2, float* dy,
                           int N, int C, int S, void* stream);
 
+/* the three steps above in one launch (one workgroup per channel); for N*S <= 65536 elements per channel */
+int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, float* dgamma, float* dbeta, float* dy, int N, int C, int S,
+                          void* stream);
+
 /* ---- stem: Conv3d(Cin->32,k3,stride (sd,sh,sw),p1,no bias) : mobilenet.py:26-31 via ssd3d.py:60-61 ------- */
 int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW);
 int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D, int H,
@@ -58,6 +63,9 @@ int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride); /* 0 naive, 1 stream, 2 resident */
 int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int C, int D, int H, int W, int stride, int force_naive, void* stream);
+/* stride-1 bwd-data as a forward pass with reversed taps on the LDS-resident kernel (-2 if the shape is not on that path) */
+int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
+                                    int accumulate, void* stream);
 int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
                         int stride, int accumulate, void* stream);
 int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int stride);
@@ -65,7 +73,7 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
 
 /* ---- pointwise Conv3d(Cin,Cout,k1) = per-image GEMM on MFMA : Block.conv2, mobilenet.py:40,45 ------------- */
-int msl_pwconv_fwd_num_partials(int N, int Cin, int S);
+int msl_pwconv_fwd_num_partials(int N, int Cin, int Cout, int S);
 int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int Cin, int Cout, int S, void* stream);
 int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,

@@ -21,6 +21,7 @@ _SIGNATURES = {
     "msl_bn_relu_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_bn_bwd_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _I, _P]),
     "msl_bn_relu_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_bn_relu_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_stem_conv_fwd_num_partials": (_I, [_I, _I, _I, _I]),
     "msl_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_stem_conv_bwd_weight_workspace_bytes": (_Z, [_I]),
@@ -28,10 +29,11 @@ _SIGNATURES = {
     "msl_dwconv_fwd_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd_variant": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_s1_bwd_data_resident": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "msl_pwconv_fwd_num_partials": (_I, [_I, _I, _I]),
+    "msl_pwconv_fwd_num_partials": (_I, [_I, _I, _I, _I]),
     "msl_pwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I]),

@@ -176,6 +176,78 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
   }
 }
 
+// Whole BatchNorm+ReLU backward of one channel in ONE workgroup (reduce -> coefficients -> apply) for the layers
+// whose per-channel data is small (<= 64 K elements: blocks 2-7).  Replaces three launches (two of them pure
+// launch latency) by one; the second pass re-reads g and y from L2.
+__global__ __launch_bounds__(256) void bn_relu_bwd_fused_kernel(
+    const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dy, int N, int C, int S, double count) {
+  __shared__ double scratch[8];
+  __shared__ float coef[2];
+  const int c = blockIdx.x;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+  const bool vec = (S & 3) == 0;
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * S;
+    if (vec) {
+      for (int i = threadIdx.x * 4; i < S; i += 1024) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
+        const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+        const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gm = fmaf(ya[k], sc, sh) > 0.f ? ga[k] : 0.f;
+          s1 += gm;
+          s2 += gm * ((ya[k] - mu) * is);
+        }
+      }
+    } else {
+      for (int i = threadIdx.x; i < S; i += 256) {
+        const float yy = y[base + i];
+        const float gm = fmaf(yy, sc, sh) > 0.f ? g[base + i] : 0.f;
+        s1 += gm;
+        s2 += gm * ((yy - mu) * is);
+      }
+    }
+  }
+  const double t1 = msl::block_sum((double)s1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+    coef[0] = (float)(t1 / count);
+    coef[1] = (float)(t2 / count);
+  }
+  __syncthreads();
+  const float k1 = coef[0], k2 = coef[1];
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * S;
+    if (vec) {
+      for (int i = threadIdx.x * 4; i < S; i += 1024) {
+        const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
+        const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
+        const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gm = fmaf(ya[k], sc, sh) > 0.f ? ga[k] : 0.f;
+          o[k] = sc * (gm - k1 - ((ya[k] - mu) * is) * k2);
+        }
+        *reinterpret_cast<float4*>(dy + base + i) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    } else {
+      for (int i = threadIdx.x; i < S; i += 256) {
+        const float yy = y[base + i];
+        const float gm = fmaf(yy, sc, sh) > 0.f ? g[base + i] : 0.f;
+        dy[base + i] = sc * (gm - k1 - ((yy - mu) * is) * k2);
+      }
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -230,6 +302,17 @@ int msl_bn_bwd_finalize(const double* partials, int num_partials, double count, 
   if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
                      count, dgamma, dbeta, c1, c2, C);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// single-launch variant (reduce + finalize + apply); intended for N*S <= 65536 elements per channel
+int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, const float* shift, const float* mean,
+                          const float* invstd, float* dgamma, float* dbeta, float* dy, int N, int C, int S,
+                          void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_relu_bwd_fused_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, y, scale, shift, mean,
+                     invstd, dgamma, dbeta, dy, N, C, S, (double)N * S);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

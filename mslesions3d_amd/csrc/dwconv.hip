@@ -306,8 +306,9 @@ template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int H,
-    int W, int OD, int OH, int OW, int G, int SLAB, int nslabs, int Nbatch) {
+    int W, int OD, int OH, int OW, int G, int SLAB, int nslabs, int Nbatch, int flip, int accumulate) {
   extern __shared__ __align__(16) float lds[];
+  const int wbase = flip ? 26 : 0, wsgn = flip ? -1 : 1;  // flipped taps: stride-1 bwd-data == forward with w[26-k]
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int slab = lb % nslabs;
   const int vg = lb / nslabs;
@@ -367,13 +368,17 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
         r.load(base + kh * RS, ow, EW);
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
-          const float ww = wc[kd * 9 + kh * 3 + kw];
+          const float ww = wc[wbase + wsgn * (kd * 9 + kh * 3 + kw)];
 #pragma unroll
           for (int v = 0; v < 4; ++v) acc[v] = fmaf(ww, r.v[kw][v], acc[v]);
         }
       }
     }
     float* yo = y + ((((size_t)n * C + c0 + g) * OD + od0 + odl) * OH + oh) * OW + ow;
+    if (accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(yo);
+      acc[0] += old.x; acc[1] += old.y; acc[2] += old.z; acc[3] += old.w;
+    }
     *reinterpret_cast<float4*>(yo) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     float s = 0.f, q = 0.f;
 #pragma unroll
@@ -546,6 +551,21 @@ int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride) {
   return make_plan(N, C, D, H, W, stride).variant;
 }
 
+// Stride-1 bwd-data is the forward convolution of dy with the taps reversed (w[26-k]); reuse the LDS-resident
+// forward kernel.  Returns MSL_ERR_UNSUPPORTED when the shape is not on the resident fast path.
+int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
+                                    int accumulate, void* stream) {
+  DwPlan pl = make_plan(N, C, D, H, W, 1);
+  if (pl.variant != 2) return MSL_ERR_UNSUPPORTED;
+  const int nblocks = N * (C / pl.G) * pl.nslabs;
+  int e_ = set_lds(dw_fwd_resident_kernel<1>, pl.lds_bytes);
+  if (e_) return e_;
+  hipLaunchKernelGGL(dw_fwd_resident_kernel<1>, dim3(nblocks), dim3(256), pl.lds_bytes, (hipStream_t)stream, dy,
+                     nullptr, nullptr, w, g_in, nullptr, C, D, H, W, D, H, W, pl.G, pl.SLAB, pl.nslabs, N, 1, accumulate);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
 int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int C, int D, int H, int W, int stride, int force_naive,
                    void* stream) {
@@ -591,12 +611,12 @@ int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift,
       int e_ = set_lds(dw_fwd_resident_kernel<2>, pl.lds_bytes);
       if (e_) return e_;
       hipLaunchKernelGGL(dw_fwd_resident_kernel<2>, dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
-                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N);
+                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
     } else {
       int e_ = set_lds(dw_fwd_resident_kernel<1>, pl.lds_bytes);
       if (e_) return e_;
       hipLaunchKernelGGL(dw_fwd_resident_kernel<1>, dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
-                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N);
+                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
     }
   }
   MSL_LAUNCH_CHECK();

@@ -275,6 +275,9 @@ __global__ __launch_bounds__(64) void dw_bwd_weight_finalize_kernel(const double
 
 }  // namespace
 
+extern "C" int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in, int N, int C, int D, int H,
+                                               int W, int accumulate, void* stream);
+
 extern "C" {
 
 // dy (N,C,OD,OH,OW) -> g_in (N,C,D,H,W); accumulate != 0 adds into g_in
@@ -283,6 +286,10 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {
+    const int rc = msl_dwconv_s1_bwd_data_resident(dy, w, g_in, N, C, D, H, W, accumulate, stream);
+    if (rc != MSL_ERR_UNSUPPORTED) return rc;
+  }
   if (W % 4 == 0) {
     if (stride == 2) {
       dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);

@@ -413,16 +413,22 @@ BwPlan bw_plan(int N, int Cin, int Cout, int S) {
 
 extern "C" {
 
-static inline bool use_ksplit(int K) { return K >= 128 && K % 128 == 0; }
+// K-split pays when the plain 64 x 128 tiling cannot fill the chip (tail layers); with >= 256 plain tiles the
+// serial-K kernel wins (no cross-wave reduction).
+static inline bool use_ksplit(int K, int M, int S, int N) {
+  return K >= 128 && K % 128 == 0 && msl::cdiv(S, BN) * msl::cdiv(M, BM) * N < 256;
+}
 
-int msl_pwconv_fwd_num_partials(int N, int Cin, int S) { return N * msl::cdiv(S, use_ksplit(Cin) ? KS_BN : BN); }
+int msl_pwconv_fwd_num_partials(int N, int Cin, int Cout, int S) {
+  return N * msl::cdiv(S, use_ksplit(Cin, Cout, S, N) ? KS_BN : BN);
+}
 
 // z (N,Cin,S) raw + input affine -> y (N,Cout,S) raw + stat partials [2][Cout][NP]
 int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int Cin, int Cout, int S, void* stream) {
   if (N <= 0 || S <= 0 || Cin % BK != 0 || Cout % 4 != 0) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (use_ksplit(Cin)) {
+  if (use_ksplit(Cin, Cout, S, N)) {
     dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cout, KS_BM), N);
     if (in_scale) {
       if (partials) hipLaunchKernelGGL((pw_gemm_ksplit_kernel<true, true, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
@@ -450,7 +456,7 @@ int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift,
 int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,
                         void* stream) {
   if (N <= 0 || S <= 0 || Cout % BK != 0 || Cin % 4 != 0) return MSL_ERR_ARG;
-  if (use_ksplit(Cout)) {
+  if (use_ksplit(Cout, Cin, S, N)) {
     dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cin, KS_BM), N);
     hipLaunchKernelGGL((pw_gemm_ksplit_kernel<false, false, true>), g2, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
                        nullptr, w, g_in, nullptr, Cin, Cout, S);

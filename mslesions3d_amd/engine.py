@@ -123,7 +123,7 @@ class Plan:
                 self.bn_z.append(torch.zeros((BN_ROWS, sp["cin"]), **f32))
                 part_elems = max(part_elems,
                                  2 * sp["cin"] * L.msl_dwconv_fwd_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]),
-                                 2 * sp["cout"] * L.msl_pwconv_fwd_num_partials(N, sp["cin"], S))
+                                 2 * sp["cout"] * L.msl_pwconv_fwd_num_partials(N, sp["cin"], sp["cout"], S))
                 if need_grad:
                     part_elems = max(part_elems,
                                      sp["cin"] * 27 * L.msl_dwconv_bwd_weight_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]),
@@ -291,7 +291,7 @@ class Engine:
                          N * S, training, st)
             self._k(f"pw_fwd{i}", "msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(blk.conv2.weight),
                       ptr(pl.y[i]), pp, N, sp["cin"], sp["cout"], S, st)
-            self._bn_fwd(blk.bn2, pl.bn_y[i], part, L.msl_pwconv_fwd_num_partials(N, sp["cin"], S), N * S, training, st)
+            self._bn_fwd(blk.bn2, pl.bn_y[i], part, L.msl_pwconv_fwd_num_partials(N, sp["cin"], sp["cout"], S), N * S, training, st)
             if i in pl.fpad:
                 plain = None
                 if want_features:
@@ -322,6 +322,10 @@ class Engine:
         """In place: g (= dL/d relu(bn(y))) becomes dL/dy; writes dgamma/dbeta into the gradient arena."""
         L = _lib.load()
         gv = self.arena.grad_views
+        if N * S <= 65536:  # small per-channel data: reduce + finalize + apply in one launch
+            self._k("bn_bwd_fused:" + bn_name, "msl_bn_relu_bwd_fused", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]),
+                    ptr(vec[2]), ptr(vec[3]), ptr(gv[bn_name + ".weight"]), ptr(gv[bn_name + ".bias"]), ptr(g), N, C, S, st)
+            return
         NP = L.msl_bn_relu_bwd_num_partials(N, S)
         self._k("bn_bwd_reduce:" + bn_name, "msl_bn_relu_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(pl.partials), N, C, S, st)

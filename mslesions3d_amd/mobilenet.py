@@ -107,13 +107,13 @@ class Block(nn.Module):
         st = _stream()
         z = torch.empty((N, C, od, oh, ow), dtype=torch.float32, device=x.device)
         NP = L.msl_dwconv_fwd_num_partials(N, C, D, H, W, s)
-        part = torch.empty(2 * max(C * NP, Cout * L.msl_pwconv_fwd_num_partials(N, C, S)), dtype=torch.float64, device=x.device)
+        part = torch.empty(2 * max(C * NP, Cout * L.msl_pwconv_fwd_num_partials(N, C, Cout, S)), dtype=torch.float64, device=x.device)
         pp = ptr(part) if self.training else None
         _lib.call("msl_dwconv_fwd", ptr(x), None, None, ptr(self.conv1.weight), ptr(z), pp, N, C, D, H, W, s, 0, st)
         v1 = _bn_vectors(self.bn1, part, NP, N * S, C, x.device, self.training)
         y = torch.empty((N, Cout, od, oh, ow), dtype=torch.float32, device=x.device)
         _lib.call("msl_pwconv_fwd", ptr(z), ptr(v1[0]), ptr(v1[1]), ptr(self.conv2.weight), ptr(y), pp, N, C, Cout, S, st)
-        v2 = _bn_vectors(self.bn2, part, L.msl_pwconv_fwd_num_partials(N, C, S), N * S, Cout, x.device, self.training)
+        v2 = _bn_vectors(self.bn2, part, L.msl_pwconv_fwd_num_partials(N, C, Cout, S), N * S, Cout, x.device, self.training)
         out = _materialize(y, v2)
         if torch.isnan(out).sum() > 0:  # mobilenet.py:46-48
             raise Exception("NaN Loss in MobileNet Block")

@@ -160,7 +160,7 @@ def test_pw_fwd_bwd(N, Cin, Cout, S):
     a = torch.relu(z * sc.view(1, -1, 1) + sh.view(1, -1, 1)).requires_grad_(True)
     ref = torch.einsum("oc,ncs->nos", w, a)
     y = torch.full(ref.shape, float("nan"), device=DEV)
-    NP = L.msl_pwconv_fwd_num_partials(N, Cin, S)
+    NP = L.msl_pwconv_fwd_num_partials(N, Cin, Cout, S)
     part = torch.zeros(2 * Cout * NP, dtype=torch.float64, device=DEV)
     _lib.call("msl_pwconv_fwd", ptr(K(z)), ptr(K(sc)), ptr(K(sh)), ptr(K(w.detach())), ptr(y), ptr(part),
               N, Cin, Cout, S, st())
@@ -223,6 +223,14 @@ def test_bn_forward_backward():
     close(dgam, gamma.grad, 1e-4, 1e-5, "dgamma")
     close(dbet, beta.grad, 1e-4, 1e-5, "dbeta")
     close(gd, y.grad, 1e-4, 1e-5, "bn bwd dy")
+    # single-launch variant
+    g2 = K(g)
+    dg2, db2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.call("msl_bn_relu_bwd_fused", ptr(g2), ptr(yd32), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(dg2), ptr(db2),
+              ptr(g2), N, C, S, st())
+    close(dg2, gamma.grad, 1e-4, 1e-5, "fused dgamma")
+    close(db2, beta.grad, 1e-4, 1e-5, "fused dbeta")
+    close(g2, y.grad, 1e-4, 1e-5, "fused bn bwd dy")
     # eval affine
     _lib.call("msl_bn_eval_affine", ptr(K(gamma.detach())), ptr(K(beta.detach())), ptr(rm_d), ptr(rv_d), 1e-5,
               ptr(vec[0]), ptr(vec[1]), C, st())
