@@ -68,6 +68,10 @@ int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in
                                     int accumulate, void* stream);
 int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
                         int stride, int accumulate, void* stream);
+/* bwd-weight on the LDS-tiled forward machinery (-2 / -1 when the shape is on the generic path) */
+int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in_scale, const float* in_shift,
+                                double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
+int msl_dwconv_bwd_weight_tiled_num_partials(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream);

@@ -31,6 +31,8 @@ _SIGNATURES = {
     "msl_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_s1_bwd_data_resident": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_weight_tiled": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_weight_tiled_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_bwd_weight_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_pwconv_fwd_num_partials": (_I, [_I, _I, _I, _I]),

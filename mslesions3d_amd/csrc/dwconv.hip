@@ -92,7 +92,29 @@ __device__ __forceinline__ void emit_stats(const float* it_s, const float* it_q,
 // "stream" variant.  Workgroup = (n, c, slab of SLAB output planes); the channel is workgroup-uniform, so
 // weights and the input affine live in SGPRs.  IPT items per thread (item = 4 adjacent outputs along W of
 // one output row); LPT float4 prefetch registers per thread.
-template <int STRIDE, int IPT, int LPT>
+// MODE 0: forward.  MODE 1: bwd-weight — the same streamed/staged input, `y` holds dy (read-only) and the 27 tap
+// sums dw[c][k] = sum dy[o] * a[o*s-1+k] of this workgroup's slab are emitted as fp64 partials [C*27][NP].
+__device__ __forceinline__ float dot4(const float4 d, const float* v) {
+  return fmaf(d.w, v[3], fmaf(d.z, v[2], fmaf(d.y, v[1], d.x * v[0])));
+}
+
+// Fixed-order reduction of 27 per-thread sums over a segment of `seglen` threads per channel g; red = [27][256].
+__device__ __forceinline__ void emit_bww(float* red, const float* a27, int G, int seglen, int c0, double* partials,
+                                         int NP, int p) {
+#pragma unroll
+  for (int k = 0; k < 27; ++k) red[k * 256 + threadIdx.x] = a27[k];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int pair = wv; pair < G * 27; pair += 4) {
+    const int g = pair / 27, k = pair % 27;
+    double s = 0.0;
+    for (int i = lane; i < seglen; i += 64) s += (double)red[k * 256 + g * seglen + i];
+    s = msl::wave_sum(s);
+    if (lane == 0) partials[((size_t)(c0 + g) * 27 + k) * NP + p] = s;
+  }
+}
+
+template <int STRIDE, int IPT, int LPT, int MODE>
 __global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int H,
@@ -116,7 +138,7 @@ __global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
   const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
   float wk[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) wk[k] = w[c * 27 + k];  // uniform -> scalar registers
+  for (int k = 0; k < 27; ++k) wk[k] = MODE == 0 ? w[c * 27 + k] : 0.f;  // uniform -> scalar registers
 
   // zero the tile once: halo rows/columns are never written again
   for (int i = threadIdx.x; i < PS; i += 256) lds[i] = 0.f;
@@ -135,6 +157,9 @@ __global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
 
   float acc_a[IPT][4], acc_b[IPT][4];  // stride 2: a = current od.  stride 1: a = od p-1, b = od p
   float st_s[IPT], st_q[IPT];
+  float a27[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) a27[k] = 0.f;
 #pragma unroll
   for (int t = 0; t < IPT; ++t) {
     st_s[t] = st_q[t] = 0.f;
@@ -196,23 +221,116 @@ __global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
     __syncthreads();
     if (p < p_end) issue_loads(p + 1);  // in flight while this plane is consumed
 
-    if (STRIDE == 2) {
-      if (p & 1) {
-        const int od_done = (p - 1) >> 1;
+    if constexpr (MODE == 1) {
+      if (pvalid) {
+        const float* dyc = yc;
+        // output planes this input plane meets, by tap kd: stride 2: odd p -> kd 0 with (p+1)/2, kd 2 with (p-1)/2;
+        // even p -> kd 1 with p/2.  stride 1: kd 0,1,2 with p+1, p, p-1.  Only planes of this slab count.
+        int odk[3];
+        if (STRIDE == 2) {
+          odk[0] = (p & 1) ? (p + 1) >> 1 : -1;
+          odk[1] = (p & 1) ? -1 : p >> 1;
+          odk[2] = (p & 1) ? (p - 1) >> 1 : -1;
+        } else {
+          odk[0] = p + 1; odk[1] = p; odk[2] = p - 1;
+        }
 #pragma unroll
+        for (int t = 0; t < IPT; ++t) {
+          if (!it_ok[t]) continue;
+          float4 dv[3];
+#pragma unroll
+          for (int kd = 0; kd < 3; ++kd) {
+            const bool use = odk[kd] >= od0 && odk[kd] < od1;
+            dv[kd] = use ? *reinterpret_cast<const float4*>(dyc + (size_t)odk[kd] * oplane + it_out[t])
+                         : make_float4(0.f, 0.f, 0.f, 0.f);
+          }
+#pragma unroll
+          for (int kh = 0; kh < 3; ++kh) {
+            RowTaps<STRIDE> r;
+            r.load(lds + it_lds[t] + kh * RS, 0, EW);
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+              if (STRIDE == 2) {
+                if (p & 1) {
+                  a27[kh * 3 + kw] += dot4(dv[0], r.v[kw]);
+                  a27[18 + kh * 3 + kw] += dot4(dv[2], r.v[kw]);
+                } else {
+                  a27[9 + kh * 3 + kw] += dot4(dv[1], r.v[kw]);
+                }
+              } else {
+#pragma unroll
+                for (int kd = 0; kd < 3; ++kd) a27[kd * 9 + kh * 3 + kw] += dot4(dv[kd], r.v[kw]);
+              }
+            }
+          }
+        }
+      }
+    } else {
+      if (STRIDE == 2) {
+        if (p & 1) {
+          const int od_done = (p - 1) >> 1;
+  #pragma unroll
+          for (int t = 0; t < IPT; ++t) {
+            if (!it_ok[t]) continue;
+            float nxt[4] = {0.f, 0.f, 0.f, 0.f};
+            if (pvalid) {
+  #pragma unroll
+              for (int kh = 0; kh < 3; ++kh) {
+                RowTaps<2> r;
+                r.load(lds + it_lds[t] + kh * RS, 0, EW);
+  #pragma unroll
+                for (int kw = 0; kw < 3; ++kw)
+  #pragma unroll
+                  for (int v = 0; v < 4; ++v) {
+                    acc_a[t][v] = fmaf(wk[18 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
+                    nxt[v] = fmaf(wk[kh * 3 + kw], r.v[kw][v], nxt[v]);
+                  }
+              }
+            }
+            if (od_done >= od0) {
+              *reinterpret_cast<float4*>(yc + (size_t)od_done * oplane + it_out[t]) =
+                  make_float4(acc_a[t][0], acc_a[t][1], acc_a[t][2], acc_a[t][3]);
+  #pragma unroll
+              for (int v = 0; v < 4; ++v) {
+                st_s[t] += acc_a[t][v];
+                st_q[t] = fmaf(acc_a[t][v], acc_a[t][v], st_q[t]);
+              }
+            }
+  #pragma unroll
+            for (int v = 0; v < 4; ++v) acc_a[t][v] = nxt[v];
+          }
+        } else if (pvalid) {
+  #pragma unroll
+          for (int t = 0; t < IPT; ++t) {
+            if (!it_ok[t]) continue;
+  #pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+              RowTaps<2> r;
+              r.load(lds + it_lds[t] + kh * RS, 0, EW);
+  #pragma unroll
+              for (int kw = 0; kw < 3; ++kw)
+  #pragma unroll
+                for (int v = 0; v < 4; ++v) acc_a[t][v] = fmaf(wk[9 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
+            }
+          }
+        }
+      } else {
+        const int od_done = p - 1;
+  #pragma unroll
         for (int t = 0; t < IPT; ++t) {
           if (!it_ok[t]) continue;
           float nxt[4] = {0.f, 0.f, 0.f, 0.f};
           if (pvalid) {
-#pragma unroll
+  #pragma unroll
             for (int kh = 0; kh < 3; ++kh) {
-              RowTaps<2> r;
+              RowTaps<1> r;
               r.load(lds + it_lds[t] + kh * RS, 0, EW);
-#pragma unroll
+  #pragma unroll
               for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
+  #pragma unroll
                 for (int v = 0; v < 4; ++v) {
                   acc_a[t][v] = fmaf(wk[18 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
+                  acc_b[t][v] = fmaf(wk[9 + kh * 3 + kw], r.v[kw][v], acc_b[t][v]);
                   nxt[v] = fmaf(wk[kh * 3 + kw], r.v[kw][v], nxt[v]);
                 }
             }
@@ -220,70 +338,26 @@ __global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
           if (od_done >= od0) {
             *reinterpret_cast<float4*>(yc + (size_t)od_done * oplane + it_out[t]) =
                 make_float4(acc_a[t][0], acc_a[t][1], acc_a[t][2], acc_a[t][3]);
-#pragma unroll
+  #pragma unroll
             for (int v = 0; v < 4; ++v) {
               st_s[t] += acc_a[t][v];
               st_q[t] = fmaf(acc_a[t][v], acc_a[t][v], st_q[t]);
             }
           }
-#pragma unroll
-          for (int v = 0; v < 4; ++v) acc_a[t][v] = nxt[v];
-        }
-      } else if (pvalid) {
-#pragma unroll
-        for (int t = 0; t < IPT; ++t) {
-          if (!it_ok[t]) continue;
-#pragma unroll
-          for (int kh = 0; kh < 3; ++kh) {
-            RowTaps<2> r;
-            r.load(lds + it_lds[t] + kh * RS, 0, EW);
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-              for (int v = 0; v < 4; ++v) acc_a[t][v] = fmaf(wk[9 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
-          }
-        }
-      }
-    } else {
-      const int od_done = p - 1;
-#pragma unroll
-      for (int t = 0; t < IPT; ++t) {
-        if (!it_ok[t]) continue;
-        float nxt[4] = {0.f, 0.f, 0.f, 0.f};
-        if (pvalid) {
-#pragma unroll
-          for (int kh = 0; kh < 3; ++kh) {
-            RowTaps<1> r;
-            r.load(lds + it_lds[t] + kh * RS, 0, EW);
-#pragma unroll
-            for (int kw = 0; kw < 3; ++kw)
-#pragma unroll
-              for (int v = 0; v < 4; ++v) {
-                acc_a[t][v] = fmaf(wk[18 + kh * 3 + kw], r.v[kw][v], acc_a[t][v]);
-                acc_b[t][v] = fmaf(wk[9 + kh * 3 + kw], r.v[kw][v], acc_b[t][v]);
-                nxt[v] = fmaf(wk[kh * 3 + kw], r.v[kw][v], nxt[v]);
-              }
-          }
-        }
-        if (od_done >= od0) {
-          *reinterpret_cast<float4*>(yc + (size_t)od_done * oplane + it_out[t]) =
-              make_float4(acc_a[t][0], acc_a[t][1], acc_a[t][2], acc_a[t][3]);
-#pragma unroll
+  #pragma unroll
           for (int v = 0; v < 4; ++v) {
-            st_s[t] += acc_a[t][v];
-            st_q[t] = fmaf(acc_a[t][v], acc_a[t][v], st_q[t]);
+            acc_a[t][v] = acc_b[t][v];
+            acc_b[t][v] = nxt[v];
           }
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) {
-          acc_a[t][v] = acc_b[t][v];
-          acc_b[t][v] = nxt[v];
         }
       }
     }
   }
 
-  if (partials) {
+  if constexpr (MODE == 1) {
+    __syncthreads();  // the tile is no longer read; reuse it as the [27][256] reduction buffer
+    emit_bww(lds, a27, 1, 256, c, partials, Nbatch * nslabs, n * nslabs + slab);
+  } else if (partials) {
     __syncthreads();
     float* it_s = lds;
     float* it_q = lds + nitems;
@@ -302,7 +376,7 @@ __global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // "resident" variant: the whole input slab (+ zero halo) of G channels in LDS.
-template <int STRIDE>
+template <int STRIDE, int MODE>
 __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int H,
@@ -350,6 +424,34 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
   }
   __syncthreads();
 
+  if constexpr (MODE == 1) {
+    float a27[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) a27[k] = 0.f;
+    const float* dyc = y;
+    for (int item = threadIdx.x; item < nitems; item += 256) {
+      const int g = item / L, r0 = item % L;
+      const int odl = r0 / Lp, r1 = r0 % Lp;
+      const int oh = r1 / OWV, ow = (r1 % OWV) * 4;
+      const float4 dv = *reinterpret_cast<const float4*>(dyc + ((((size_t)n * C + c0 + g) * OD + od0 + odl) * OH + oh) * OW + ow);
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const float* base = lds + g * CS + (STRIDE * odl + kd) * PS + (STRIDE * oh) * RS;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          RowTaps<STRIDE> r;
+          r.load(base + kh * RS, ow, EW);
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) a27[kd * 9 + kh * 3 + kw] += dot4(dv, r.v[kw]);
+        }
+      }
+    }
+    __syncthreads();  // tile reads done: reuse the LDS as the [27][256] reduction buffer
+    // G == 1: every thread's items belong to channel c0 (idle threads hold zeros); G > 1: one item per thread and
+    // channel g owns the L consecutive threads [g*L, (g+1)*L)
+    emit_bww(lds, a27, G, G == 1 ? 256 : L, c0, partials, Nbatch * nslabs, n * nslabs + slab);
+    return;
+  }
   // stats scratch lives after the tile
   float* it_s = lds + G * CS;
   float* it_q = it_s + nitems;
@@ -551,6 +653,57 @@ int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride) {
   return make_plan(N, C, D, H, W, stride).variant;
 }
 
+// bwd-weight on the LDS-tiled kernels (MODE 1).  Returns MSL_ERR_UNSUPPORTED for shapes on the generic path.
+// partials: fp64 [C*27][NP], NP = msl_dwconv_bwd_weight_num_partials().
+int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in_scale, const float* in_shift,
+                                double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
+  const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  DwPlan pl = make_plan(N, C, D, H, W, stride);
+  // many channels per workgroup (tiny tail volumes): the per-channel epilogue reduction dominates and the
+  // barrier-free wave-per-item kernel of dwconv_bwd.hip is faster
+  if (pl.variant == 0 || pl.G > 4) return MSL_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblocks = N * (C / pl.G) * pl.nslabs;
+  const size_t lds = std::max(pl.lds_bytes, (size_t)27 * 256 * sizeof(float));
+  float* dyp = const_cast<float*>(dy);
+  if (pl.variant == 1) {
+#define MSL_DW_BWW(S_, I_, L_)                                                                                  \
+  do {                                                                                                          \
+    int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_, 1>, lds);                                                 \
+    if (e_) return e_;                                                                                          \
+    hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale,   \
+                       in_shift, nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N);        \
+  } while (0)
+    if (stride == 2) {
+      if (pl.ipt == 1 && pl.lpt == 4) MSL_DW_BWW(2, 1, 4);
+      else MSL_DW_BWW(2, 4, 12);
+    } else {
+      if (pl.ipt == 1 && pl.lpt == 4) MSL_DW_BWW(1, 1, 4);
+      else MSL_DW_BWW(1, 4, 12);
+    }
+#undef MSL_DW_BWW
+  } else {
+    if (stride == 2) {
+      int e_ = set_lds(dw_fwd_resident_kernel<2, 1>, lds);
+      if (e_) return e_;
+      hipLaunchKernelGGL((dw_fwd_resident_kernel<2, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
+                         nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
+    } else {
+      int e_ = set_lds(dw_fwd_resident_kernel<1, 1>, lds);
+      if (e_) return e_;
+      hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
+                         nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
+    }
+  }
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_dwconv_bwd_weight_tiled_num_partials(int N, int C, int D, int H, int W, int stride) {
+  DwPlan pl = make_plan(N, C, D, H, W, stride);
+  return (pl.variant == 0 || pl.G > 4) ? -1 : pl.num_partials;
+}
+
 // Stride-1 bwd-data is the forward convolution of dy with the taps reversed (w[26-k]); reuse the LDS-resident
 // forward kernel.  Returns MSL_ERR_UNSUPPORTED when the shape is not on the resident fast path.
 int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
@@ -558,9 +711,9 @@ int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in
   DwPlan pl = make_plan(N, C, D, H, W, 1);
   if (pl.variant != 2) return MSL_ERR_UNSUPPORTED;
   const int nblocks = N * (C / pl.G) * pl.nslabs;
-  int e_ = set_lds(dw_fwd_resident_kernel<1>, pl.lds_bytes);
+  int e_ = set_lds(dw_fwd_resident_kernel<1, 0>, pl.lds_bytes);
   if (e_) return e_;
-  hipLaunchKernelGGL(dw_fwd_resident_kernel<1>, dim3(nblocks), dim3(256), pl.lds_bytes, (hipStream_t)stream, dy,
+  hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, (hipStream_t)stream, dy,
                      nullptr, nullptr, w, g_in, nullptr, C, D, H, W, D, H, W, pl.G, pl.SLAB, pl.nslabs, N, 1, accumulate);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -593,9 +746,9 @@ int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift,
   if (pl.variant == 1) {
 #define MSL_DW_STREAM(S_, I_, L_)                                                                              \
   do {                                                                                                         \
-    int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_>, pl.lds_bytes);                                          \
+    int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_, 0>, pl.lds_bytes);                                          \
     if (e_) return e_;                                                                                         \
-    hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x,      \
+    hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x,      \
                        in_scale, in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N);        \
   } while (0)
     if (stride == 2) {
@@ -608,14 +761,14 @@ int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift,
 #undef MSL_DW_STREAM
   } else {
     if (stride == 2) {
-      int e_ = set_lds(dw_fwd_resident_kernel<2>, pl.lds_bytes);
+      int e_ = set_lds(dw_fwd_resident_kernel<2, 0>, pl.lds_bytes);
       if (e_) return e_;
-      hipLaunchKernelGGL(dw_fwd_resident_kernel<2>, dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
+      hipLaunchKernelGGL((dw_fwd_resident_kernel<2, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
                          in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
     } else {
-      int e_ = set_lds(dw_fwd_resident_kernel<1>, pl.lds_bytes);
+      int e_ = set_lds(dw_fwd_resident_kernel<1, 0>, pl.lds_bytes);
       if (e_) return e_;
-      hipLaunchKernelGGL(dw_fwd_resident_kernel<1>, dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
+      hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
                          in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
     }
   }

@@ -275,6 +275,9 @@ __global__ __launch_bounds__(64) void dw_bwd_weight_finalize_kernel(const double
 
 }  // namespace
 
+extern "C" int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in_scale, const float* in_shift,
+                                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
+extern "C" int msl_dwconv_bwd_weight_tiled_num_partials(int N, int C, int D, int H, int W, int stride);
 extern "C" int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in, int N, int C, int D, int H,
                                                int W, int accumulate, void* stream);
 
@@ -307,6 +310,8 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
 }
 
 int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int stride) {
+  const int tiled = msl_dwconv_bwd_weight_tiled_num_partials(N, C, D, H, W, stride);
+  if (tiled > 0) return tiled;
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   return N * msl::cdiv(OD * OH * OW, BW_CHUNK);
 }
@@ -316,8 +321,18 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
-  const int chunks = msl::cdiv(OD * OH * OW, BW_CHUNK);
   hipStream_t st = (hipStream_t)stream;
+  {
+    const int rc = msl_dwconv_bwd_weight_tiled(dy, x, in_scale, in_shift, partials, N, C, D, H, W, stride, stream);
+    if (rc == MSL_OK) {
+      const int NPt = msl_dwconv_bwd_weight_tiled_num_partials(N, C, D, H, W, stride);
+      hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, NPt, dw, C * 27);
+      MSL_LAUNCH_CHECK();
+      return MSL_OK;
+    }
+    if (rc != MSL_ERR_UNSUPPORTED) return rc;
+  }
+  const int chunks = msl::cdiv(OD * OH * OW, BW_CHUNK);
   const int total_items = N * C * chunks;
   hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(msl::cdiv(total_items, 4)), dim3(256), 0, st, dy, x, in_scale, in_shift,
                      partials, C, D, H, W, OD, OH, OW, stride, chunks, N * chunks, total_items);

@@ -124,7 +124,12 @@ def test_dw_fwd(N, C, dims, stride, variant, affine):
 
 
 @pytest.mark.parametrize("N,C,dims,stride", [(2, 4, (8, 16, 16), 2), (2, 4, (8, 16, 16), 1), (1, 3, (5, 7, 9), 2),
-                                              (1, 3, (5, 7, 9), 1), (1, 2, (9, 12, 20), 2)])
+                                              (1, 3, (5, 7, 9), 1), (1, 2, (9, 12, 20), 2),
+                                              # LDS-tiled bwd-weight: streamed planes (1/4 items per thread), resident
+                                              # slabs with several channels per workgroup, odd depth
+                                              (1, 4, (10, 40, 40), 2), (1, 3, (9, 40, 48), 1), (1, 2, (7, 96, 96), 2),
+                                              (2, 64, (8, 8, 8), 2), (2, 64, (4, 4, 4), 1), (2, 16, (32, 32, 32), 2),
+                                              (1, 8, (5, 8, 8), 1)])
 def test_dw_bwd(N, C, dims, stride):
     L = _lib.load()
     x = rnd(N, C, *dims, seed=4)
