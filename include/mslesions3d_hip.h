@@ -145,6 +145,11 @@ int msl_detect_objects(const float* locs, const float* scores, const float* prio
 int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp,
                   const unsigned char* is_bias, int n, void* stream);
 int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream);
+/* stream fork/join (hipEvent with timing disabled): record on the producer stream, wait on the consumer stream */
+int msl_event_create(void** out);
+int msl_event_destroy(void* ev);
+int msl_event_record(void* ev, void* stream);
+int msl_stream_wait_event(void* stream, void* ev);
 /* asynchronous 32-bit fill (used to clear flags / counters inside a launch sequence) */
 int msl_fill_u32(void* dst, unsigned int value, size_t count, void* stream);
 

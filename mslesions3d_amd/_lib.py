@@ -59,6 +59,10 @@ _SIGNATURES = {
     "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "msl_nan_flag": (_I, [_P, _Z, _P, _I, _P]),
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
+    "msl_event_create": (_I, [_P]),
+    "msl_event_destroy": (_I, [_P]),
+    "msl_event_record": (_I, [_P, _P]),
+    "msl_stream_wait_event": (_I, [_P, _P]),
 }
 
 _lib = None
@@ -88,6 +92,13 @@ def load():
 
 def exported_names():
     return sorted(_SIGNATURES.keys())
+
+
+def new_event():
+    """A hipEvent (timing disabled) as an opaque integer handle."""
+    out = ctypes.c_void_p()
+    check(load().msl_event_create(ctypes.byref(out)), "msl_event_create")
+    return out.value
 
 
 def ptr(t):

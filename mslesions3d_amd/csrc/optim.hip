@@ -66,6 +66,20 @@ int msl_fill_u32(void* dst, unsigned int value, size_t count, void* stream) {
   return e == hipSuccess ? MSL_OK : (int)e;
 }
 
+// ---- stream fork / join primitives (so that a multi-stream schedule can live inside a recorded launch program)
+int msl_event_create(void** out) {
+  hipEvent_t ev;
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+  if (e != hipSuccess) return (int)e;
+  *out = (void*)ev;
+  return MSL_OK;
+}
+int msl_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
+int msl_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
+int msl_stream_wait_event(void* stream, void* ev) {
+  return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
+}
+
 int msl_abi_version(void) { return 1; }
 
 }  // extern "C"

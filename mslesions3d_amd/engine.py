@@ -165,13 +165,26 @@ class Plan:
                 D, H, W = self.dims[i]
                 ws = max(ws, L.msl_pwconv_bwd_weight_workspace_bytes(N, specs[i]["cin"], specs[i]["cout"], D * H * W))
             self.ws = torch.empty(max(ws // 4, 1), **f32)
+            # private scratch of the weight-gradient stream (its kernels overlap the main stream's)
+            self.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
+            self.partials_w = torch.empty_like(self.partials)
+        self.events = {}
         self.saved_input = None
         self.generation = 0
 
 
 class Engine:
+    """Schedule: the main stream carries the dependency chain (backbone forward; activation-gradient chain in
+    backward).  Two side streams take what is off that chain and too small to fill 256 CUs on its own:
+    * ``heads``  — forward: the head convolutions of scales 3 and 5 run beside backbone blocks 4-7; backward: their
+      weight / data gradients run beside the backward of blocks 7..4;
+    * ``wgrad``  — every pointwise / depthwise weight gradient runs beside the next layer's data-gradient chain.
+    Forks and joins are hipEvents recorded through the C ABI, so the schedule survives launch-program replay."""
+
     def __init__(self, model):
         self.model = model
+        self.multi_stream = True
+        self.side = {}
         self.arena = None
         self.plans = {}
         self.prof, self.prof_tags = None, None
@@ -204,6 +217,27 @@ class Engine:
     @staticmethod
     def _stream():
         return torch.cuda.current_stream().cuda_stream
+
+    def side_streams(self, device):
+        """(heads, wgrad) torch streams for ``device`` (created once)."""
+        key = (device.type, device.index)
+        if key not in self.side:
+            self.side[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        return self.side[key]
+
+    @staticmethod
+    def _event(pl, name):
+        ev = pl.events.get(name)
+        if ev is None:
+            ev = pl.events[name] = _lib.new_event()
+        return ev
+
+    @classmethod
+    def _fork(cls, pl, name, src, dst):
+        """dst stream waits for everything enqueued on src so far."""
+        ev = cls._event(pl, name)
+        _lib.call("msl_event_record", ev, src, tag="event")
+        _lib.call("msl_stream_wait_event", dst, ev, tag="event")
 
     # -- optional per-launch HIP-event timing (bench.py's roofline leg) -------------------------------------
     def start_profile(self, tags=None):
@@ -263,6 +297,7 @@ class Engine:
         pl.saved_input = x
         pl.trained_mode = training
         st = self._stream()
+        stH = self.side_streams(x.device)[0].cuda_stream if self.multi_stream else st
         N = pl.N
         feats = m.base.features
         specs = self.layer_specs
@@ -299,23 +334,29 @@ class Engine:
                     out_feats[i] = plain
                 self._k(f"materialize{i}", "msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]), ptr(pl.bn_y[i][1]), ptr(plain),
                           ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
-        self._heads_forward(pl, st)
+                # this scale's head convolution only needs the feature map: run it beside the remaining blocks
+                last = i == len(specs) - 1
+                if self.multi_stream and not last:
+                    self._fork(pl, f"fwd_feat{i}", st, stH)
+                self._head_forward(pl, i, st if (last or not self.multi_stream) else stH)
+        if self.multi_stream:
+            self._fork(pl, "fwd_heads_done", stH, st)
         _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
         _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
         if want_features:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores
 
-    def _heads_forward(self, pl, st):
+    def _head_forward(self, pl, f, st):
         m = self.model
         ncls = m.n_classes
-        for k, f in enumerate(pl.feat_ids):
-            lc, cc = m.pred_convs.loc_convs[k], m.pred_convs.cl_convs[k]
-            C = self.layer_specs[f]["cout"]
-            D, H, W = pl.dims[f]
-            self._k(f"head_pack{f}", "msl_head_pack_weights", ptr(lc.weight), ptr(cc.weight), ptr(pl.Wf[f]), ptr(pl.Wb[f]), C, ncls, st)
-            self._k(f"head_fwd{f}", "msl_head_conv_fwd", ptr(pl.fpad[f]), ptr(pl.Wf[f]), ptr(lc.bias), ptr(cc.bias), ptr(pl.locs),
-                      ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
+        k = pl.feat_ids.index(f)
+        lc, cc = m.pred_convs.loc_convs[k], m.pred_convs.cl_convs[k]
+        C = self.layer_specs[f]["cout"]
+        D, H, W = pl.dims[f]
+        self._k(f"head_pack{f}", "msl_head_pack_weights", ptr(lc.weight), ptr(cc.weight), ptr(pl.Wf[f]), ptr(pl.Wb[f]), C, ncls, st)
+        self._k(f"head_fwd{f}", "msl_head_conv_fwd", ptr(pl.fpad[f]), ptr(pl.Wf[f]), ptr(lc.bias), ptr(cc.bias), ptr(pl.locs),
+                ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
 
     # ------------------------------------------------------------------------------------------------
     def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st):
@@ -334,32 +375,64 @@ class Engine:
         self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(vec[4]), ptr(vec[5]), ptr(g), N, C, S, st)
 
+    def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None):
+        m, gv, ncls = self.model, self.arena.grad_views, self.model.n_classes
+        k = pl.feat_ids.index(f)
+        C = self.layer_specs[f]["cout"]
+        D, H, W = pl.dims[f]
+        self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), pl.N, D, H, W, pl.P,
+                pl.prior_off[f], ncls, st)
+        pre = f"pred_convs.loc_convs.{k}", f"pred_convs.cl_convs.{k}"
+        self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), pl.N, C, D, H, W, ncls, st)
+        if data_done_event is not None:  # the activation-gradient chain only waits for the data gradient
+            _lib.call("msl_event_record", data_done_event, st, tag="event")
+        self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
+                ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
+                ptr(pl.head_ws[f]), pl.N, C, D, H, W, ncls, st)
+
     def backward(self, pl, dlocs, dscores, on_bucket_ready=None):
-        """Given dL/dlocs, dL/dscores, fill the flat gradient arena.  ``on_bucket_ready(k)`` is called right after
-        the launches that complete gradient bucket k (0 = heads .. last = stem) have been enqueued."""
+        """Given dL/dlocs, dL/dscores, fill the flat gradient arena.  ``on_bucket_ready(stage)`` is called right
+        after the launches that complete a gradient stage ('heads', 7, ..., 0) have been enqueued; if it has a
+        ``stages`` attribute only those stages are reported (and the side streams are joined first)."""
         if not pl.need_grad or not pl.trained_mode:
             raise RuntimeError("backward needs a train-mode forward made with gradients enabled")
         m = self.model
         gv = self.arena.grad_views
         st = self._stream()
-        N, ncls = pl.N, m.n_classes
+        ms = self.multi_stream
+        if ms:
+            sH, sW = self.side_streams(pl.locs.device)
+            stH, stW = sH.cuda_stream, sW.cuda_stream
+        else:
+            stH = stW = st
+        N = pl.N
         specs = self.layer_specs
         feats = m.base.features
         dlocs = dlocs.contiguous()
         dscores = dscores.contiguous()
-        # heads
-        for k, f in enumerate(pl.feat_ids):
-            C = specs[f]["cout"]
-            D, H, W = pl.dims[f]
-            self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P, pl.prior_off[f],
-                      ncls, st)
-            pre = f"pred_convs.loc_convs.{k}", f"pred_convs.cl_convs.{k}"
-            self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
-                      ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
-                      ptr(pl.head_ws[f]), N, C, D, H, W, ncls, st)
-            self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W, ncls, st)
-        self._hook(on_bucket_ready, "heads")
+        wanted = getattr(on_bucket_ready, "stages", None)
+
+        def report(stage, join_heads=False):
+            if on_bucket_ready is None or (wanted is not None and stage not in wanted):
+                return
+            if ms:  # the communication stream follows the main stream: bring the side streams' work in first
+                self._fork(pl, f"bucket_w{stage}", stW, st)
+                if join_heads:
+                    self._fork(pl, f"bucket_h{stage}", stH, st)
+            self._hook(on_bucket_ready, stage)
+
+        # heads: the last scale feeds the chain immediately (main stream); the earlier scales are only needed when
+        # the chain reaches their feature map, so they run on the heads stream beside blocks 7..4
         last = len(specs) - 1
+        side_feats = [f for f in pl.feat_ids if f != last] if ms else []
+        if side_feats:
+            self._fork(pl, "bwd_loss_ready", st, stH)
+            for f in reversed(side_feats):  # the deeper scale is needed first
+                self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}"))
+        for f in pl.feat_ids:
+            if f not in side_feats:
+                self._head_backward(pl, f, dlocs, dscores, st)
+        report("heads", join_heads=True)
         for i in range(last, 0, -1):
             sp = specs[i]
             D, H, W = pl.dims[i]
@@ -369,21 +442,27 @@ class Engine:
             name = f"base.features.{i}"
             if i not in pl.fpad and i == last:
                 raise RuntimeError("the last backbone feature must feed a head")
-            # y_i = pw(relu(bn1(z_i))): BN2 backward, then the two GEMMs
+            # y_i = pw(relu(bn1(z_i))): BN2 backward, then the two GEMMs (weight gradient on the wgrad stream)
             self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st)
+            if ms:
+                self._fork(pl, f"dy{i}", st, stW)
             self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
-                      ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, st)
+                    ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, stW)
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
-                      sp["cout"], S, st)
-            # z_i = dw(relu(bn(y_{i-1}))): BN1 backward, then depthwise bwd-weight / bwd-data
+                    sp["cout"], S, st)
+            # z_i = dw(relu(bn(y_{i-1}))): BN1 backward, then depthwise bwd-weight (wgrad stream) / bwd-data
             self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
+            if ms:
+                self._fork(pl, f"dz{i}", st, stW)
             self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
-                      ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials), N, sp["cin"], pd, ph,
-                      pw, s, st)
+                    ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w if ms else pl.partials), N,
+                    sp["cin"], pd, ph, pw, s, stW)
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
+            if accumulate and (i - 1) in side_feats:
+                _lib.call("msl_stream_wait_event", st, pl.events[f"head_done{i - 1}"], tag="event")
             self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
-                      sp["cin"], pd, ph, pw, s, accumulate, st)
-            self._hook(on_bucket_ready, i)
+                    sp["cin"], pd, ph, pw, s, accumulate, st)
+            report(i)
         # stem
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
@@ -391,8 +470,11 @@ class Engine:
         D, H, W = pl.in_dims
         sd, sh, sw = specs[0]["stride"]
         self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]),
-                  ptr(pl.ws), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
-        self._hook(on_bucket_ready, 0)
+                ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
+        if ms:  # every gradient is complete once the side streams have been joined
+            self._fork(pl, "bwd_join_w", stW, st)
+            self._fork(pl, "bwd_join_h", stH, st)
+        report(0)
 
     def check_nan(self, pl):
         """One host sync: raise like ssd3d.py:258-261 if the forward produced NaN."""

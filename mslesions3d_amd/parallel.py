@@ -37,6 +37,11 @@ class GradBucketReducer:
             self.trigger.setdefault(stg, []).append(k)
         self.comm_stream = torch.cuda.Stream() if self.world > 1 and arena.grad.is_cuda else None
         self.pending = []
+        # Engine.backward only reports (and joins its side streams for) the stages that complete a bucket
+        self.stages = set(self.trigger.keys()) if self.world > 1 else set()
+
+    def __call__(self, stage):
+        self.on_stage(stage)
 
     def on_stage(self, stage):
         """Engine.backward calls this right after enqueueing the kernels of ``stage``."""

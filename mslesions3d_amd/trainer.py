@@ -47,7 +47,7 @@ class FusedTrainer:
         _lib.call("msl_multibox_loss_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
                   ptr(st["loss_out"]), ptr(st["upstream_alpha"]), ptr(st["dlocs"]), ptr(st["dscores"]), N, P, ncls,
                   torch.cuda.current_stream().cuda_stream)
-        eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red.on_stage)
+        eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red)
         scale = red.finish()
         _lib.record_hook(red.finish, tag="hook:finish")
         self.opt.step(grad_scale=scale, gather_autograd_grads=False)

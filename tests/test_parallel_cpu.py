@@ -37,6 +37,7 @@ def _worker(rank, world, port, n_buckets, result_dir):
         assert red.ranges[0][0] == 0 and red.ranges[-1][1] == arena.n_trainable
         assert all(a[1] == b[0] for a, b in zip(red.ranges, red.ranges[1:]))
         assert sorted(k for ks in red.trigger.values() for k in ks) == list(range(len(red.ranges)))
+        assert red.stages == set(red.trigger.keys())
         # fake backward: every parameter's gradient becomes available at its stage
         g = torch.Generator().manual_seed(7 + rank)
         local = torch.randn(arena.n_trainable, generator=g)
