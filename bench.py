@@ -114,6 +114,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     run(args.steps)
+    t_host = time.perf_counter() - t0  # host-side enqueue time (diagnostic only)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -159,6 +160,7 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": len(ms)},
         }
+        print(f"host enqueue {t_host / args.steps * 1e3:.3f} ms/step of {dt / args.steps * 1e3:.3f} ms/step wall", file=sys.stderr)
         if args.profile_all:
             rows = sorted(((sum(v) / len(v), t, len(v)) for t, v in prof.items()), reverse=True)
             tot = sum(r[0] for r in rows)

@@ -128,6 +128,11 @@ int msl_multibox_loss_bwd(const float* locs, const float* scores, const long lon
                           const float* true_locs, const float* loss_out, const float* upstream, float* dlocs,
                           float* dscores, int N, int P, int ncls, void* stream);
 
+/* loss forward + backward for the training loop (2 launches; publishes loss_out as above) */
+int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long long* true_classes,
+                              const float* true_locs, double* workspace, float* loss_out, const float* upstream,
+                              float* dlocs, float* dscores, int N, int P, int ncls, void* stream);
+
 /* ---- LSSD3D.detect_objects (ssd3d.py:344-460): softmax, decode, filter, sort, 3D NMS, top-k ---------------
  * cap = 10*top_k (<= 4096), Wn = ceil(cap/64), K1 = ncls-1.  Caller-allocated scratch:
  *   probs (N,K1,P) f32; boxes (N,P,6) f32; sorted_idx (N,K1,cap) i32; ncand (N*K1) i32;

@@ -11,21 +11,28 @@
 
 namespace {
 
-__global__ __launch_bounds__(64) void bn_finalize_kernel(
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
     const double* __restrict__ partials, int NP, double count, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
     long long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ scale,
     float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int C) {
+  __shared__ double scratch[8];
   const int c = blockIdx.x, lane = threadIdx.x;
   double s = 0.0, q = 0.0;
   const double* ps = partials + (size_t)c * NP;
   const double* pq = partials + ((size_t)C + c) * NP;
-  for (int p = lane; p < NP; p += 64) {
+  for (int p = lane; p < NP; p += blockDim.x) {
     s += ps[p];
     q += pq[p];
   }
-  s = msl::wave_sum(s);
-  q = msl::wave_sum(q);
+  if (blockDim.x == 64) {
+    s = msl::wave_sum(s);
+    q = msl::wave_sum(q);
+  } else {  // fixed order: lanes within a wave, then waves 0..3
+    s = msl::block_sum(s, scratch);
+    __syncthreads();
+    q = msl::block_sum(q, scratch);
+  }
   if (lane == 0) {
     const double mean = s / count;
     double var = q / count - mean * mean;
@@ -257,7 +264,7 @@ int msl_bn_finalize(const double* partials, int num_partials, double count, cons
                     long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift,
                     float* save_mean, float* save_invstd, int C, void* stream) {
   if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(num_partials > 256 ? 256 : 64), 0, (hipStream_t)stream, partials, num_partials,
                      count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                      shift, save_mean, save_invstd, C);
   MSL_LAUNCH_CHECK();

@@ -295,17 +295,47 @@ __global__ void multibox_loss_finalize_kernel(const double* __restrict__ partial
   out[2] = npf;
 }
 
+template <bool FROM_PARTIALS>
 __global__ __launch_bounds__(256) void multibox_loss_bwd_kernel(const float* __restrict__ locs,
                                                                 const float* __restrict__ scores,
                                                                 const long long* __restrict__ true_classes,
                                                                 const float* __restrict__ true_locs,
-                                                                const float* __restrict__ loss_out,
+                                                                float* __restrict__ loss_out,
+                                                                const double* __restrict__ partials, int nparts,
                                                                 const float* __restrict__ upstream,
                                                                 float* __restrict__ dlocs, float* __restrict__ dscores,
                                                                 int total, int ncls) {
+  __shared__ float s_np;
   const int i = blockIdx.x * 256 + threadIdx.x;
+  float npf;
+  if (FROM_PARTIALS) {
+    // every workgroup folds the (few) partials itself; workgroup 0 also publishes the losses -> no finalize launch
+    if (threadIdx.x < 64) {
+      double ce = 0.0, l1 = 0.0, np = 0.0;
+      for (int k = threadIdx.x; k < nparts; k += 64) {
+        ce += partials[k * 3 + 0];
+        l1 += partials[k * 3 + 1];
+        np += partials[k * 3 + 2];
+      }
+      ce = msl::wave_sum(ce);
+      l1 = msl::wave_sum(l1);
+      np = msl::wave_sum(np);
+      if (threadIdx.x == 0) {
+        const float f = (float)np;
+        s_np = f;
+        if (blockIdx.x == 0) {
+          loss_out[0] = (float)ce / f;
+          loss_out[1] = (float)l1 / (f * 6.0f);
+          loss_out[2] = f;
+        }
+      }
+    }
+    __syncthreads();
+    npf = s_np;
+  } else {
+    npf = loss_out[2];
+  }
   if (i >= total) return;
-  const float npf = loss_out[2];
   const float gc = upstream[0] / npf, gl = upstream[1] / (npf * 6.0f);
   const long long tc = true_classes[i];
   const float* x = scores + (size_t)i * ncls;
@@ -414,8 +444,25 @@ int msl_multibox_loss_bwd(const float* locs, const float* scores, const long lon
                           const float* true_locs, const float* loss_out, const float* upstream, float* dlocs,
                           float* dscores, int N, int P, int ncls, void* stream) {
   if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(multibox_loss_bwd_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream, locs,
-                     scores, true_classes, true_locs, loss_out, upstream, dlocs, dscores, N * P, ncls);
+  hipLaunchKernelGGL(multibox_loss_bwd_kernel<false>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream,
+                     locs, scores, true_classes, true_locs, const_cast<float*>(loss_out), nullptr, 0, upstream, dlocs,
+                     dscores, N * P, ncls);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// forward + backward of the loss in two launches (training hot loop): the backward kernel folds the forward's
+// partials itself and publishes loss_out = [conf, loc, n_positives]
+int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long long* true_classes,
+                              const float* true_locs, double* workspace, float* loss_out, const float* upstream,
+                              float* dlocs, float* dscores, int N, int P, int ncls, void* stream) {
+  if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
+                     true_locs, workspace, N * P, ncls);
+  MSL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(multibox_loss_bwd_kernel<true>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores,
+                     true_classes, true_locs, loss_out, workspace, LOSS_BLOCKS, upstream, dlocs, dscores, N * P, ncls);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -133,20 +133,20 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
 constexpr int KS_BM = 32, KS_BN = 64;
 constexpr int KS_WAVE_LDS = BK * KS_BN + KS_BM * WS_LD;  // floats per wave
 
-template <bool AFFINE, bool STATS, bool TRANS_W>
-__global__ __launch_bounds__(256) void pw_gemm_ksplit_kernel(const float* __restrict__ X,
+template <bool AFFINE, bool STATS, bool TRANS_W, int NW>
+__global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __restrict__ X,
                                                              const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift,
                                                              const float* __restrict__ Wt, float* __restrict__ Y,
                                                              double* __restrict__ partials, int M, int K, int S) {
-  __shared__ __align__(16) float lds[4 * KS_WAVE_LDS];
+  extern __shared__ __align__(16) float lds[];  // NW * KS_WAVE_LDS floats
   const int n = blockIdx.z, m0 = blockIdx.y * KS_BM, s0 = blockIdx.x * KS_BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float* Xs = lds + wv * KS_WAVE_LDS;   // [BK][KS_BN]
   float* Ws = Xs + BK * KS_BN;          // [KS_BM][WS_LD]
   const float* Xn = X + (size_t)n * K * S;
   const bool vec_ok = (S & 3) == 0;
-  const int kq = K >> 2;                // K range of this wave
+  const int kq = K / NW;                // K range of this wave
   const int kbeg = wv * kq;
   const int nchunks = kq / BK;
 
@@ -224,23 +224,28 @@ __global__ __launch_bounds__(256) void pw_gemm_ksplit_kernel(const float* __rest
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
     }
   }
-  // fixed-order reduction over the 4 K-quarters: 3, 2, 1 into LDS, wave 0 adds its own and finishes
+  // fixed-order tree reduction over the NW K-slices: the upper half of the live waves parks its tile in LDS, the
+  // lower half adds it, until wave 0 holds the sum
   __syncthreads();
-  float* red = lds;  // [32][64 + 1]
   constexpr int RLD = KS_BN + 1;
-  for (int w2 = 3; w2 >= 1; --w2) {
-    if (wv == w2) {
+  for (int half = NW / 2; half >= 1; half >>= 1) {
+    if (wv >= half && wv < 2 * half) {
+      float* slot = lds + (wv - half) * (KS_BM * RLD);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        float* p0 = red + row * RLD + (lane & 31);
-        if (w2 == 3) {
-          p0[0] = acc0[r];
-          p0[32] = acc1[r];
-        } else {
-          p0[0] += acc0[r];
-          p0[32] += acc1[r];
-        }
+        slot[row * RLD + (lane & 31)] = acc0[r];
+        slot[row * RLD + 32 + (lane & 31)] = acc1[r];
+      }
+    }
+    __syncthreads();
+    if (wv < half) {
+      const float* slot = lds + wv * (KS_BM * RLD);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        acc0[r] += slot[row * RLD + (lane & 31)];
+        acc1[r] += slot[row * RLD + 32 + (lane & 31)];
       }
     }
     __syncthreads();
@@ -252,8 +257,8 @@ __global__ __launch_bounds__(256) void pw_gemm_ksplit_kernel(const float* __rest
   for (int r = 0; r < 16; ++r) {
     const int rl = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
     const int row = m0 + rl;
-    const float v0 = acc0[r] + red[rl * RLD + (lane & 31)];
-    const float v1 = acc1[r] + red[rl * RLD + 32 + (lane & 31)];
+    const float v0 = acc0[r];
+    const float v1 = acc1[r];
     if (row < M && colbase < S) Yn[(size_t)row * S + colbase] = v0;
     if (row < M && colbase + 32 < S) Yn[(size_t)row * S + colbase + 32] = v1;
     if (STATS) {
@@ -430,12 +435,26 @@ int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift,
   hipStream_t st = (hipStream_t)stream;
   if (use_ksplit(Cin, Cout, S, N)) {
     dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cout, KS_BM), N);
+#define MSL_KS(A_, S_, T_, X_, Wp_, Y_, P_, M_, K_)                                                                  \
+  do {                                                                                                             \
+    if ((K_) % 256 == 0) {                                                                                         \
+      const size_t lds_ = (size_t)8 * KS_WAVE_LDS * sizeof(float);                                                 \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_ksplit_kernel<A_, S_, T_, 8>),    \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                  \
+      if (e_ != hipSuccess) return (int)e_;                                                                        \
+      hipLaunchKernelGGL((pw_gemm_ksplit_kernel<A_, S_, T_, 8>), g2, dim3(512), lds_, st, X_, in_scale, in_shift,  \
+                         Wp_, Y_, P_, M_, K_, S);                                                                  \
+    } else {                                                                                                       \
+      hipLaunchKernelGGL((pw_gemm_ksplit_kernel<A_, S_, T_, 4>), g2, dim3(256),                                    \
+                         (size_t)4 * KS_WAVE_LDS * sizeof(float), st, X_, in_scale, in_shift, Wp_, Y_, P_, M_, K_, S); \
+    }                                                                                                              \
+  } while (0)
     if (in_scale) {
-      if (partials) hipLaunchKernelGGL((pw_gemm_ksplit_kernel<true, true, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
-      else hipLaunchKernelGGL((pw_gemm_ksplit_kernel<true, false, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+      if (partials) MSL_KS(true, true, false, z, w, y, partials, Cout, Cin);
+      else MSL_KS(true, false, false, z, w, y, partials, Cout, Cin);
     } else {
-      if (partials) hipLaunchKernelGGL((pw_gemm_ksplit_kernel<false, true, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
-      else hipLaunchKernelGGL((pw_gemm_ksplit_kernel<false, false, false>), g2, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+      if (partials) MSL_KS(false, true, false, z, w, y, partials, Cout, Cin);
+      else MSL_KS(false, false, false, z, w, y, partials, Cout, Cin);
     }
     MSL_LAUNCH_CHECK();
     return MSL_OK;
@@ -458,8 +477,10 @@ int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
   if (N <= 0 || S <= 0 || Cout % BK != 0 || Cin % 4 != 0) return MSL_ERR_ARG;
   if (use_ksplit(Cout, Cin, S, N)) {
     dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cin, KS_BM), N);
-    hipLaunchKernelGGL((pw_gemm_ksplit_kernel<false, false, true>), g2, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
-                       nullptr, w, g_in, nullptr, Cin, Cout, S);
+    hipStream_t st = (hipStream_t)stream;
+    const float *in_scale = nullptr, *in_shift = nullptr;
+    double* nopart = nullptr;
+    MSL_KS(false, false, true, dy, w, g_in, nopart, Cin, Cout);
     MSL_LAUNCH_CHECK();
     return MSL_OK;
   }

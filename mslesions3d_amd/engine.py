@@ -375,7 +375,7 @@ class Engine:
         self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(vec[4]), ptr(vec[5]), ptr(g), N, C, S, st)
 
-    def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None):
+    def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None, st_weight=None):
         m, gv, ncls = self.model, self.arena.grad_views, self.model.n_classes
         k = pl.feat_ids.index(f)
         C = self.layer_specs[f]["cout"]
@@ -386,6 +386,9 @@ class Engine:
         self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), pl.N, C, D, H, W, ncls, st)
         if data_done_event is not None:  # the activation-gradient chain only waits for the data gradient
             _lib.call("msl_event_record", data_done_event, st, tag="event")
+        if st_weight is not None and st_weight != st:  # weight gradient on another stream: it needs dO (gpack)
+            self._fork(pl, f"head_dO{f}", st, st_weight)
+            st = st_weight
         self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
                 ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
                 ptr(pl.head_ws[f]), pl.N, C, D, H, W, ncls, st)
@@ -427,11 +430,11 @@ class Engine:
         side_feats = [f for f in pl.feat_ids if f != last] if ms else []
         if side_feats:
             self._fork(pl, "bwd_loss_ready", st, stH)
-            for f in reversed(side_feats):  # the deeper scale is needed first
-                self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}"))
-        for f in pl.feat_ids:
+        for f in pl.feat_ids:  # the chain's own scale first: its data gradient starts the backward chain
             if f not in side_feats:
-                self._head_backward(pl, f, dlocs, dscores, st)
+                self._head_backward(pl, f, dlocs, dscores, st, st_weight=stW if ms else None)
+        for f in reversed(side_feats):  # the deeper scale is needed first
+            self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}"))
         report("heads", join_heads=True)
         for i in range(last, 0, -1):
             sp = specs[i]

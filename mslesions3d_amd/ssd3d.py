@@ -617,7 +617,9 @@ class MultiBoxLoss(nn.Module):
             return float(self.threshold), 0.0, 0
         return float(self.threshold[0]), float(self.threshold[1]), 1
 
-    def _run_forward(self, st, locs, scores, gt_boxes, gt_labels, obj_off, T):
+    def _run_forward(self, st, locs, scores, gt_boxes, gt_labels, obj_off, T, with_backward_upstream=None):
+        """Matching + loss.  With ``with_backward_upstream`` (a 2-float device tensor [dL/dconf, dL/dloc]) the loss
+        gradient w.r.t. locs / scores is produced in the same call (training hot loop)."""
         N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
         assert P == self.priors_cxcycz.size(0) == scores.size(1)  # ssd3d.py:845
         lo, hi, soft = self._thresholds()
@@ -625,6 +627,11 @@ class MultiBoxLoss(nn.Module):
         _lib.call("msl_multibox_match", ptr(gt_boxes), ptr(gt_labels), ptr(obj_off), T, ptr(self.priors_cxcycz), N, P, lo,
                   hi, soft, ptr(st["overlap"]), ptr(st["obj"]), ptr(st["prior_for_obj"]), ptr(st["true_classes"]),
                   ptr(st["true_locs"]), ptr(st["matched"]), sm)
+        if with_backward_upstream is not None:
+            _lib.call("msl_multibox_loss_fwd_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
+                      ptr(st["ws"]), ptr(st["loss_out"]), ptr(with_backward_upstream), ptr(st["dlocs"]), ptr(st["dscores"]),
+                      N, P, ncls, sm)
+            return
         _lib.call("msl_multibox_loss_fwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
                   ptr(st["ws"]), ptr(st["loss_out"]), N, P, ncls, sm)
 

@@ -40,13 +40,11 @@ class FusedTrainer:
         pl = eng.plan_for(images, True)
         N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
         st = lf._state(N, P, ncls, total_objects, dev)
-        lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects)
         if "upstream_alpha" not in st or st["upstream_alpha_value"] != float(lf.alpha):
             st["upstream_alpha"] = torch.tensor([1.0, float(lf.alpha)], dtype=torch.float32, device=dev)  # loss = conf + alpha*loc
             st["upstream_alpha_value"] = float(lf.alpha)
-        _lib.call("msl_multibox_loss_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
-                  ptr(st["loss_out"]), ptr(st["upstream_alpha"]), ptr(st["dlocs"]), ptr(st["dscores"]), N, P, ncls,
-                  torch.cuda.current_stream().cuda_stream)
+        lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects,
+                        with_backward_upstream=st["upstream_alpha"])
         eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red)
         scale = red.finish()
         _lib.record_hook(red.finish, tag="hook:finish")
