@@ -155,6 +155,12 @@ int msl_event_create(void** out);
 int msl_event_destroy(void* ev);
 int msl_event_record(void* ev, void* stream);
 int msl_stream_wait_event(void* stream, void* ev);
+/* capture everything enqueued on `stream` (and on streams forked from it) between begin and end into an executable
+ * HIP graph; relaunch it with msl_graph_launch */
+int msl_graph_begin(void* stream);
+int msl_graph_end(void* stream, void** exec_out);
+int msl_graph_launch(void* exec, void* stream);
+int msl_graph_destroy(void* exec);
 /* asynchronous 32-bit fill (used to clear flags / counters inside a launch sequence) */
 int msl_fill_u32(void* dst, unsigned int value, size_t count, void* stream);
 

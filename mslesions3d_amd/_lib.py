@@ -60,6 +60,10 @@ _SIGNATURES = {
     "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "msl_nan_flag": (_I, [_P, _Z, _P, _I, _P]),
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
+    "msl_graph_begin": (_I, [_P]),
+    "msl_graph_end": (_I, [_P, _P]),
+    "msl_graph_launch": (_I, [_P, _P]),
+    "msl_graph_destroy": (_I, [_P]),
     "msl_event_create": (_I, [_P]),
     "msl_event_destroy": (_I, [_P]),
     "msl_event_record": (_I, [_P, _P]),
@@ -100,6 +104,56 @@ def new_event():
     out = ctypes.c_void_p()
     check(load().msl_event_create(ctypes.byref(out)), "msl_event_create")
     return out.value
+
+
+def capture_graph(prog, stream):
+    """Capture a recorded launch program (single process, no Python hooks) into an executable HIP graph."""
+    if any(fn is None for fn, _, _ in prog):
+        raise HipKernelError("a launch program with Python hooks cannot be captured into a HIP graph")
+    lib = load()
+    check(lib.msl_graph_begin(stream), "msl_graph_begin")
+    try:
+        replay(prog)
+    except Exception:
+        out = ctypes.c_void_p()
+        lib.msl_graph_end(stream, ctypes.byref(out))
+        raise
+    out = ctypes.c_void_p()
+    check(lib.msl_graph_end(stream, ctypes.byref(out)), "msl_graph_end")
+    return out.value
+
+
+def capture_segments(prog, stream, split_tags):
+    """Like capture_graph, but the launches whose tag is in ``split_tags`` stay individual launches (so that an
+    event pair can be recorded around them): -> list of ("graph", exec) / ("call", (fn, args, tag)) parts."""
+    parts, cur = [], []
+    for item in prog:
+        if item[2] in split_tags and item[0] is not None:
+            if cur:
+                parts.append(("graph", capture_graph(cur, stream)))
+                cur = []
+            parts.append(("call", item))
+        else:
+            cur.append(item)
+    if cur:
+        parts.append(("graph", capture_graph(cur, stream)))
+    return parts
+
+
+def run_segments(parts, stream, sink, event_factory):
+    lib = load()
+    for kind, payload in parts:
+        if kind == "graph":
+            check(lib.msl_graph_launch(payload, stream), "msl_graph_launch")
+        else:
+            fn, args, tag = payload
+            e0, e1 = event_factory(), event_factory()
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            sink.setdefault(tag, []).append((e0, e1))
+            if rc:
+                check(rc, tag)
 
 
 def ptr(t):

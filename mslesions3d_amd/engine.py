@@ -233,6 +233,16 @@ class Engine:
         return ev
 
     @classmethod
+    def _record(cls, pl, name, stream):
+        ev = cls._event(pl, name)
+        _lib.call("msl_event_record", ev, stream, tag="event")
+        return ev
+
+    @staticmethod
+    def _wait(stream, ev):
+        _lib.call("msl_stream_wait_event", stream, ev, tag="event")
+
+    @classmethod
     def _fork(cls, pl, name, src, dst):
         """dst stream waits for everything enqueued on src so far."""
         ev = cls._event(pl, name)
@@ -314,6 +324,7 @@ class Engine:
         self._bn_fwd(feats[0][1], pl.bn_y[0], part, L.msl_stem_conv_fwd_num_partials(N, od, oh, ow),
                      N * od * oh * ow, training, st)
         out_feats = {}
+        deferred = []
         for i in range(1, len(specs)):
             sp, blk = specs[i], feats[i]
             pd, ph, pw = pl.dims[i - 1]
@@ -337,8 +348,18 @@ class Engine:
                 # this scale's head convolution only needs the feature map: run it beside the remaining blocks
                 last = i == len(specs) - 1
                 if self.multi_stream and not last:
-                    self._fork(pl, f"fwd_feat{i}", st, stH)
-                self._head_forward(pl, i, st if (last or not self.multi_stream) else stH)
+                    # record now, launch the head after the NEXT block's kernels have been enqueued (host order
+                    # decides which queue starves; the backbone chain must never wait for the host)
+                    ev = self._record(pl, f"fwd_feat{i}", st)
+                    deferred.append(lambda ev=ev, i=i: (self._wait(stH, ev), self._head_forward(pl, i, stH)))
+                else:
+                    self._head_forward(pl, i, st)
+            elif deferred:
+                for fn in deferred:
+                    fn()
+                deferred = []
+        for fn in deferred:
+            fn()
         if self.multi_stream:
             self._fork(pl, "fwd_heads_done", stH, st)
         _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
@@ -375,20 +396,20 @@ class Engine:
         self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(vec[4]), ptr(vec[5]), ptr(g), N, C, S, st)
 
-    def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None, st_weight=None):
+    def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None, data=True, weight=True):
         m, gv, ncls = self.model, self.arena.grad_views, self.model.n_classes
         k = pl.feat_ids.index(f)
         C = self.layer_specs[f]["cout"]
         D, H, W = pl.dims[f]
-        self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), pl.N, D, H, W, pl.P,
-                pl.prior_off[f], ncls, st)
         pre = f"pred_convs.loc_convs.{k}", f"pred_convs.cl_convs.{k}"
-        self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), pl.N, C, D, H, W, ncls, st)
-        if data_done_event is not None:  # the activation-gradient chain only waits for the data gradient
-            _lib.call("msl_event_record", data_done_event, st, tag="event")
-        if st_weight is not None and st_weight != st:  # weight gradient on another stream: it needs dO (gpack)
-            self._fork(pl, f"head_dO{f}", st, st_weight)
-            st = st_weight
+        if data:
+            self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), pl.N, D, H, W, pl.P,
+                    pl.prior_off[f], ncls, st)
+            self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), pl.N, C, D, H, W, ncls, st)
+            if data_done_event is not None:  # the activation-gradient chain only waits for the data gradient
+                _lib.call("msl_event_record", data_done_event, st, tag="event")
+        if not weight:
+            return
         self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
                 ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
                 ptr(pl.head_ws[f]), pl.N, C, D, H, W, ncls, st)
@@ -430,11 +451,22 @@ class Engine:
         side_feats = [f for f in pl.feat_ids if f != last] if ms else []
         if side_feats:
             self._fork(pl, "bwd_loss_ready", st, stH)
+        pending = []  # side-stream launches, issued one layer late so that the chain's launches always go first
         for f in pl.feat_ids:  # the chain's own scale first: its data gradient starts the backward chain
             if f not in side_feats:
-                self._head_backward(pl, f, dlocs, dscores, st, st_weight=stW if ms else None)
+                if ms:
+                    self._head_backward(pl, f, dlocs, dscores, st, weight=False)
+                    ev = self._record(pl, f"head_dO{f}", st)
+                    pending.append(lambda f=f, ev=ev: (self._wait(stW, ev),
+                                                       self._head_backward(pl, f, dlocs, dscores, stW, data=False)))
+                else:
+                    self._head_backward(pl, f, dlocs, dscores, st)
         for f in reversed(side_feats):  # the deeper scale is needed first
-            self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}"))
+            pending.append(lambda f=f: self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}")))
+        if wanted is not None and "heads" in wanted:
+            for fn in pending:
+                fn()
+            pending = []
         report("heads", join_heads=True)
         for i in range(last, 0, -1):
             sp = specs[i]
@@ -445,26 +477,42 @@ class Engine:
             name = f"base.features.{i}"
             if i not in pl.fpad and i == last:
                 raise RuntimeError("the last backbone feature must feed a head")
-            # y_i = pw(relu(bn1(z_i))): BN2 backward, then the two GEMMs (weight gradient on the wgrad stream)
+            # y_i = pw(relu(bn1(z_i))): BN2 backward, then the two GEMMs; z_i = dw(relu(bn(y_{i-1}))): BN1 backward,
+            # then the depthwise gradients.  The host enqueues the dependency chain (main stream) FIRST and the two
+            # weight gradients (wgrad stream, waiting on events recorded in the chain) afterwards: the chain is made of
+            # ~10 us kernels, so any launch queued in front of its next link shows up as idle time.
             self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st)
-            if ms:
-                self._fork(pl, f"dy{i}", st, stW)
-            self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
-                    ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, stW)
+            ev_dy = self._record(pl, f"dy{i}", st) if ms else None
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
                     sp["cout"], S, st)
-            # z_i = dw(relu(bn(y_{i-1}))): BN1 backward, then depthwise bwd-weight (wgrad stream) / bwd-data
             self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
-            if ms:
-                self._fork(pl, f"dz{i}", st, stW)
-            self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
-                    ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w if ms else pl.partials), N,
-                    sp["cin"], pd, ph, pw, s, stW)
+            ev_dz = self._record(pl, f"dz{i}", st) if ms else None
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
             if accumulate and (i - 1) in side_feats:
-                _lib.call("msl_stream_wait_event", st, pl.events[f"head_done{i - 1}"], tag="event")
+                self._wait(st, pl.events[f"head_done{i - 1}"])
             self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
                     sp["cin"], pd, ph, pw, s, accumulate, st)
+            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dy=ev_dy, ev_dz=ev_dz):
+                if ms:
+                    self._wait(stW, ev_dy)
+                self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
+                        ptr(pl.bn_z[i][1]), ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, stW)
+                if ms:
+                    self._wait(stW, ev_dz)
+                self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
+                        ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w if ms else pl.partials),
+                        N, sp["cin"], pd, ph, pw, s, stW)
+
+            # issue what the previous layer left for the side streams, then queue this layer's
+            for fn in pending:
+                fn()
+            pending = [wgrads] if ms else []
+            if not ms:
+                wgrads()
+            if wanted is not None and i in wanted:
+                for fn in pending:
+                    fn()
+                pending = []
             report(i)
         # stem
         od, oh, ow = pl.dims[0]
@@ -474,6 +522,8 @@ class Engine:
         sd, sh, sw = specs[0]["stride"]
         self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]),
                 ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
+        for fn in pending:
+            fn()
         if ms:  # every gradient is complete once the side streams have been joined
             self._fork(pl, "bwd_join_w", stW, st)
             self._fork(pl, "bwd_join_h", stH, st)
