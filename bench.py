@@ -121,6 +121,15 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = eng.stop_profile()
+    # diagnostic: pure host cost of enqueueing one step (GPU idle, empty queues -> no back-pressure)
+    t_enq = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run(1)
+        t_enq.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    t_host1 = sorted(t_enq)[len(t_enq) // 2]
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -160,7 +169,8 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": len(ms)},
         }
-        print(f"host enqueue {t_host / args.steps * 1e3:.3f} ms/step of {dt / args.steps * 1e3:.3f} ms/step wall", file=sys.stderr)
+        print(f"host enqueue {t_host / args.steps * 1e3:.3f} ms/step of {dt / args.steps * 1e3:.3f} ms/step wall; "
+              f"one step into empty queues: {t_host1 * 1e3:.3f} ms", file=sys.stderr)
         if args.profile_all:
             rows = sorted(((sum(v) / len(v), t, len(v)) for t, v in prof.items()), reverse=True)
             tot = sum(r[0] for r in rows)

@@ -161,6 +161,10 @@ int msl_graph_begin(void* stream);
 int msl_graph_end(void* stream, void** exec_out);
 int msl_graph_launch(void* exec, void* stream);
 int msl_graph_destroy(void* exec);
+/* native replay of a recorded launch sequence (generated trampolines, csrc/gen_runner.py): fn_ids from
+ * msl_program_fn_id(); slots = n x stride raw 64-bit argument values; *failed_at = index of the failing call */
+int msl_program_fn_id(const char* name);
+int msl_run_program(const int* fn_ids, const unsigned long long* slots, int stride, int n, int* failed_at);
 /* asynchronous 32-bit fill (used to clear flags / counters inside a launch sequence) */
 int msl_fill_u32(void* dst, unsigned int value, size_t count, void* stream);
 

@@ -59,6 +59,8 @@ _SIGNATURES = {
     "msl_detect_objects": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I] + [_P] * 14 + [_P]),
     "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "msl_nan_flag": (_I, [_P, _Z, _P, _I, _P]),
+    "msl_program_fn_id": (_I, [_P]),
+    "msl_run_program": (_I, [_P, _P, _I, _I, _P]),
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
     "msl_graph_begin": (_I, [_P]),
     "msl_graph_end": (_I, [_P, _P]),
@@ -104,6 +106,81 @@ def new_event():
     out = ctypes.c_void_p()
     check(load().msl_event_create(ctypes.byref(out)), "msl_event_create")
     return out.value
+
+
+# -- native replay ----------------------------------------------------------------------------------------------
+_SLOT_STRIDE = 24
+_fn_ids = {}
+
+
+def _slot(value, ctype):
+    import struct
+    if ctype is _F:
+        return struct.unpack("<I", struct.pack("<f", value))[0]
+    if ctype is _D:
+        return struct.unpack("<Q", struct.pack("<d", value))[0]
+    if value is None:
+        return 0
+    return int(value) & 0xFFFFFFFFFFFFFFFF
+
+
+def compile_program(prog, timed_tags=()):
+    """Recorded program -> list of segments: ("native", fn_ids, slots, n, tags) runs in ONE foreign call through the
+    generated trampolines (csrc/program_runner.hip); ("hook", callable) are the Python callbacks in between;
+    launches whose tag is in ``timed_tags`` stay individual ("timed", (fn, args, tag)) so an event pair can wrap them."""
+    lib = load()
+    segs, ids, slots, tags = [], [], [], []
+
+    def flush():
+        if ids:
+            n = len(ids)
+            segs.append(("native", (ctypes.c_int * n)(*ids), (ctypes.c_ulonglong * (n * _SLOT_STRIDE))(*slots), n, list(tags)))
+            ids.clear(), slots.clear(), tags.clear()
+
+    for fn, args, tag in prog:
+        if fn is None:
+            flush()
+            segs.append(("hook", args))
+            continue
+        if tag in timed_tags:
+            flush()
+            segs.append(("timed", (fn, args, tag)))
+            continue
+        name = fn.__name__
+        fid = _fn_ids.get(name)
+        if fid is None:
+            fid = _fn_ids[name] = lib.msl_program_fn_id(name.encode())
+        if fid < 0:
+            raise HipKernelError(f"{name} cannot be replayed natively")
+        argtypes = _SIGNATURES[name][1]
+        row = [_slot(a, t) for a, t in zip(args, argtypes)]
+        assert len(row) == len(argtypes) <= _SLOT_STRIDE, name
+        ids.append(fid)
+        slots.extend(row + [0] * (_SLOT_STRIDE - len(row)))
+        tags.append(tag)
+    flush()
+    return segs
+
+
+def replay_native(segs, sink=None, event_factory=None):
+    lib = load()
+    failed = ctypes.c_int(-1)
+    for seg in segs:
+        if seg[0] == "hook":
+            seg[1]()
+        elif seg[0] == "timed":
+            fn, args, tag = seg[1]
+            e0, e1 = event_factory(), event_factory()
+            e0.record()
+            rc = fn(*args)
+            e1.record()
+            sink.setdefault(tag, []).append((e0, e1))
+            if rc:
+                check(rc, tag)
+        else:
+            rc = lib.msl_run_program(seg[1], seg[2], _SLOT_STRIDE, seg[3], ctypes.byref(failed))
+            if rc:
+                check(rc, f"launch program entry {failed.value} ({seg[4][failed.value]})")
 
 
 def capture_graph(prog, stream):

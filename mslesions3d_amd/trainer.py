@@ -104,13 +104,19 @@ class FusedTrainer:
                         parts = entry["segments"][tags] = _lib.capture_segments(prog, stream, tags)
                     _lib.run_segments(parts, stream, eng.prof, lambda: torch.cuda.Event(enable_timing=True))
                 elif eng.prof is not None:
-                    _lib.replay(prog, eng.prof_tags, eng.prof, lambda: torch.cuda.Event(enable_timing=True))
+                    tags = frozenset(eng.prof_tags)
+                    segs = entry.setdefault("native_timed", {}).get(tags)
+                    if segs is None:
+                        segs = entry["native_timed"][tags] = _lib.compile_program(prog, tags)
+                    _lib.replay_native(segs, eng.prof, lambda: torch.cuda.Event(enable_timing=True))
                 elif graph_ok:
                     if entry["graph"] is None:
                         entry["graph"] = _lib.capture_graph(prog, stream)
                     _lib.check(_lib.load().msl_graph_launch(entry["graph"], stream), "msl_graph_launch")
                 else:
-                    _lib.replay(prog)
+                    if "native" not in entry:
+                        entry["native"] = _lib.compile_program(prog)
+                    _lib.replay_native(entry["native"])
         caller.wait_stream(self._stream)
         self.last_plan = pl
         if self.sch is not None:

@@ -65,6 +65,21 @@ def test_pure_host_entry_points():
     assert lib.msl_head_packed_weight_elems(128, 2) == 128 // 4 * 27 * 64
 
 
+def test_native_program_runner_covers_the_abi():
+    """Every int-returning entry point without out-parameters has a trampoline in the generated runner."""
+    lib = _lib.load()
+    skipped = {"msl_run_program", "msl_program_fn_id", "msl_event_create", "msl_graph_end"}
+    for name, (ret, _) in _prototypes().items():
+        fid = lib.msl_program_fn_id(name.encode())
+        assert (fid >= 0) == (ret == "int" and name not in skipped), name
+    # host-only call through the runner: msl_abi_version() == 1 means rc 1 is reported as the failing code
+    import ctypes
+    ids = (ctypes.c_int * 1)(lib.msl_program_fn_id(b"msl_abi_version"))
+    slots = (ctypes.c_ulonglong * 24)()
+    failed = ctypes.c_int(-1)
+    assert lib.msl_run_program(ids, slots, 24, 1, ctypes.byref(failed)) == 1 and failed.value == 0
+
+
 def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libmsl3d_hip.so")
