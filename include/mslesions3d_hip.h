@@ -28,12 +28,22 @@ int msl_bn_finalize(const double* partials, int num_partials, double count, cons
                     float* running_mean, float* running_var, long long* num_batches_tracked, float momentum,
                     float eps, float* scale, float* shift, float* save_mean, float* save_invstd, int C,
                     void* stream);
+/* every BatchNorm of the network in one launch: fill a host table entry per layer, copy it to the device once */
+size_t msl_bn_finalize_entry_bytes(void);
+int msl_bn_finalize_table_set(void* host_table, int index, int first_block, const double* partials, int num_partials,
+                              double count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                              float* scale, float* shift, float* save_mean, float* save_invstd, int C);
+int msl_bn_finalize_batch(const void* device_table, int n_entries, int total_channels, void* stream);
 /* eval mode: scale/shift from the running statistics */
 int msl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, int C, void* stream);
 /* relu(y*scale+shift) into a plain (N,C,D,H,W) tensor and/or a zero-haloed (N,C,D+2,H+2,W+2) one (either may be NULL) */
 int msl_bn_relu_materialize(const float* y, const float* scale, const float* shift, float* out_plain,
                             float* out_pad, int N, int C, int D, int H, int W, void* stream);
+int msl_bn_relu_materialize_fold(const float* y, const double* partials, int num_partials, double count,
+                                 const float* gamma, const float* beta, float eps, float* out_plain, float* out_pad,
+                                 int N, int C, int D, int H, int W, void* stream);
 /* backward of a = relu(bn(y)):  reduce -> finalize -> apply (dy may alias g) */
 int msl_bn_relu_bwd_num_partials(int N, int S);
 int msl_bn_relu_bwd_reduce(const float* g, const float* y, const float* scale, const float* shift,
@@ -66,6 +76,10 @@ int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift,
 /* stride-1 bwd-data as a forward pass with reversed taps on the LDS-resident kernel (-2 if the shape is not on that path) */
 int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
                                     int accumulate, void* stream);
+/* forward with the input's BatchNorm folded in-kernel from the producer's partials (no finalize launch on the chain) */
+int msl_dwconv_fwd_fold(const float* x, const double* in_partials, int in_np, double in_count, const float* gamma,
+                        const float* beta, float eps, const float* w, float* y, double* partials, int N, int C, int D,
+                        int H, int W, int stride, void* stream);
 int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
                         int stride, int accumulate, void* stream);
 /* bwd-weight on the LDS-tiled forward machinery (-2 / -1 when the shape is on the generic path) */
@@ -80,6 +94,9 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
 int msl_pwconv_fwd_num_partials(int N, int Cin, int Cout, int S);
 int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int Cin, int Cout, int S, void* stream);
+int msl_pwconv_fwd_fold(const float* z, const double* in_partials, int in_np, double in_count, const float* gamma,
+                        const float* beta, float eps, const float* w, float* y, double* partials, int N, int Cin,
+                        int Cout, int S, void* stream);
 int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,
                         void* stream);
 size_t msl_pwconv_bwd_weight_workspace_bytes(int N, int Cin, int Cout, int S);
@@ -152,6 +169,8 @@ int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
 int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream);
 /* stream fork/join (hipEvent with timing disabled): record on the producer stream, wait on the consumer stream */
 int msl_event_create(void** out);
+int msl_event_create_timed(void** out);                       /* timing-enabled event (launch-duration measurements) */
+int msl_event_elapsed_ms(void* start, void* stop, float* out_ms);
 int msl_event_destroy(void* ev);
 int msl_event_record(void* ev, void* stream);
 int msl_stream_wait_event(void* stream, void* ev);

@@ -15,8 +15,12 @@ _P, _I, _F, _D, _Z, _Q = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c
 _SIGNATURES = {
     "msl_abi_version": (_I, []),
     "msl_bn_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I, _P]),
+    "msl_bn_finalize_entry_bytes": (_Z, []),
+    "msl_bn_finalize_table_set": (_I, [_P, _I, _I, _P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I]),
+    "msl_bn_finalize_batch": (_I, [_P, _I, _I, _P]),
     "msl_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "msl_bn_relu_materialize": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msl_bn_relu_materialize_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msl_bn_relu_bwd_num_partials": (_I, [_I, _I]),
     "msl_bn_relu_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_bn_bwd_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _I, _P]),
@@ -30,6 +34,7 @@ _SIGNATURES = {
     "msl_dwconv_fwd_variant": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_s1_bwd_data_resident": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_fwd_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_tiled": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_tiled_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
@@ -37,6 +42,7 @@ _SIGNATURES = {
     "msl_dwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_pwconv_fwd_num_partials": (_I, [_I, _I, _I, _I]),
     "msl_pwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_pwconv_fwd_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "msl_pwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
@@ -67,6 +73,8 @@ _SIGNATURES = {
     "msl_graph_launch": (_I, [_P, _P]),
     "msl_graph_destroy": (_I, [_P]),
     "msl_event_create": (_I, [_P]),
+    "msl_event_create_timed": (_I, [_P]),
+    "msl_event_elapsed_ms": (_I, [_P, _P, _P]),
     "msl_event_destroy": (_I, [_P]),
     "msl_event_record": (_I, [_P, _P]),
     "msl_stream_wait_event": (_I, [_P, _P]),
@@ -129,7 +137,7 @@ def compile_program(prog, timed_tags=()):
     generated trampolines (csrc/program_runner.hip); ("hook", callable) are the Python callbacks in between;
     launches whose tag is in ``timed_tags`` stay individual ("timed", (fn, args, tag)) so an event pair can wrap them."""
     lib = load()
-    segs, ids, slots, tags = [], [], [], []
+    segs, ids, slots, tags, patches = [], [], [], [], []
 
     def flush():
         if ids:
@@ -142,11 +150,15 @@ def compile_program(prog, timed_tags=()):
             flush()
             segs.append(("hook", args))
             continue
-        if tag in timed_tags:
-            flush()
-            segs.append(("timed", (fn, args, tag)))
-            continue
         name = fn.__name__
+        timed = tag in timed_tags
+        if timed:  # event record / launch / event record back to back inside the native segment
+            rec = _fn_ids.setdefault("msl_event_record", lib.msl_program_fn_id(b"msl_event_record"))
+            stream = args[-1]
+            patches.append((len(segs), len(ids) * _SLOT_STRIDE, (len(ids) + 2) * _SLOT_STRIDE, tag))
+            ids.append(rec)
+            slots.extend([0, _slot(stream, _P)] + [0] * (_SLOT_STRIDE - 2))
+            tags.append("event")
         fid = _fn_ids.get(name)
         if fid is None:
             fid = _fn_ids[name] = lib.msl_program_fn_id(name.encode())
@@ -158,25 +170,41 @@ def compile_program(prog, timed_tags=()):
         ids.append(fid)
         slots.extend(row + [0] * (_SLOT_STRIDE - len(row)))
         tags.append(tag)
+        if timed:
+            ids.append(rec)
+            slots.extend([0, _slot(stream, _P)] + [0] * (_SLOT_STRIDE - 2))
+            tags.append("event")
     flush()
-    return segs
+    return {"segments": segs, "patches": patches}
 
 
-def replay_native(segs, sink=None, event_factory=None):
+def new_timed_event():
+    out = ctypes.c_void_p()
+    check(load().msl_event_create_timed(ctypes.byref(out)), "msl_event_create_timed")
+    return out.value
+
+
+def elapsed_ms(e0, e1):
+    out = ctypes.c_float()
+    check(load().msl_event_elapsed_ms(e0, e1, ctypes.byref(out)), "msl_event_elapsed_ms")
+    return out.value
+
+
+def replay_native(compiled, sink=None):
+    """Run a compiled program.  If it has timed launches, a fresh timing-event pair is patched in around each of
+    them (sink[tag] collects ("c", start, stop) handles; read them with elapsed_ms after a synchronise)."""
     lib = load()
     failed = ctypes.c_int(-1)
+    segs = compiled["segments"]
+    for seg_i, off0, off1, tag in compiled["patches"]:
+        e0, e1 = new_timed_event(), new_timed_event()
+        segs[seg_i][2][off0] = e0
+        segs[seg_i][2][off1] = e1
+        if sink is not None:
+            sink.setdefault(tag, []).append(("c", e0, e1))
     for seg in segs:
         if seg[0] == "hook":
             seg[1]()
-        elif seg[0] == "timed":
-            fn, args, tag = seg[1]
-            e0, e1 = event_factory(), event_factory()
-            e0.record()
-            rc = fn(*args)
-            e1.record()
-            sink.setdefault(tag, []).append((e0, e1))
-            if rc:
-                check(rc, tag)
         else:
             rc = lib.msl_run_program(seg[1], seg[2], _SLOT_STRIDE, seg[3], ctypes.byref(failed))
             if rc:

@@ -11,45 +11,72 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const double* __restrict__ partials, int NP, double count, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ running_mean, float* __restrict__ running_var,
-    long long* __restrict__ num_batches_tracked, float momentum, float eps, float* __restrict__ scale,
-    float* __restrict__ shift, float* __restrict__ save_mean, float* __restrict__ save_invstd, int C) {
-  __shared__ double scratch[8];
+__global__ __launch_bounds__(64) void bn_finalize_kernel(msl::BnFold f, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var,
+                                                         long long* __restrict__ num_batches_tracked, float momentum,
+                                                         float* __restrict__ scale, float* __restrict__ shift,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd) {
   const int c = blockIdx.x, lane = threadIdx.x;
-  double s = 0.0, q = 0.0;
-  const double* ps = partials + (size_t)c * NP;
-  const double* pq = partials + ((size_t)C + c) * NP;
-  for (int p = lane; p < NP; p += blockDim.x) {
-    s += ps[p];
-    q += pq[p];
+  float sc, sh, mu, is;
+  double var;
+  if (f.NP <= 64) {
+    if (lane != 0) return;
+    msl::bn_fold_serial(f, c, sc, sh, mu, is, var);
+  } else {
+    msl::bn_fold_wave(f, c, sc, sh, mu, is, var);
+    if (lane != 0) return;
   }
-  if (blockDim.x == 64) {
-    s = msl::wave_sum(s);
-    q = msl::wave_sum(q);
-  } else {  // fixed order: lanes within a wave, then waves 0..3
-    s = msl::block_sum(s, scratch);
-    __syncthreads();
-    q = msl::block_sum(q, scratch);
+  scale[c] = sc;
+  shift[c] = sh;
+  save_mean[c] = mu;
+  save_invstd[c] = is;
+  if (running_mean) {
+    const float unbiased = (float)(f.count > 1.0 ? var * f.count / (f.count - 1.0) : var);
+    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mu;
+    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
   }
-  if (lane == 0) {
-    const double mean = s / count;
-    double var = q / count - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const double invstd = 1.0 / sqrt(var + (double)eps);
-    const double sc = (double)gamma[c] * invstd;
-    scale[c] = (float)sc;
-    shift[c] = (float)((double)beta[c] - mean * sc);
-    save_mean[c] = (float)mean;
-    save_invstd[c] = (float)invstd;
-    if (running_mean) {
-      const float unbiased = (float)(count > 1.0 ? var * count / (count - 1.0) : var);
-      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * (float)mean;
-      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * unbiased;
-    }
-    if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+  if (c == 0 && num_batches_tracked) *num_batches_tracked += 1;
+}
+
+// All BatchNorm layers of the network in one launch: entry e of the table describes one layer; workgroup b serves
+// channel (b - first_block[e]) of the entry it falls into.
+struct BnFinalizeEntry {
+  msl::BnFold fold;
+  float* running_mean;
+  float* running_var;
+  long long* num_batches_tracked;
+  float momentum;
+  float* scale;
+  float* shift;
+  float* save_mean;
+  float* save_invstd;
+  int first_block;
+};
+
+__global__ __launch_bounds__(64) void bn_finalize_batch_kernel(const BnFinalizeEntry* __restrict__ table, int n_entries) {
+  int e = 0;
+  while (e + 1 < n_entries && (int)blockIdx.x >= table[e + 1].first_block) ++e;
+  const BnFinalizeEntry t = table[e];
+  const int c = blockIdx.x - t.first_block, lane = threadIdx.x;
+  float sc, sh, mu, is;
+  double var;
+  if (t.fold.NP <= 64) {
+    if (lane != 0) return;
+    msl::bn_fold_serial(t.fold, c, sc, sh, mu, is, var);
+  } else {
+    msl::bn_fold_wave(t.fold, c, sc, sh, mu, is, var);
+    if (lane != 0) return;
   }
+  t.scale[c] = sc;
+  t.shift[c] = sh;
+  t.save_mean[c] = mu;
+  t.save_invstd[c] = is;
+  if (t.running_mean) {
+    const float unbiased = (float)(t.fold.count > 1.0 ? var * t.fold.count / (t.fold.count - 1.0) : var);
+    t.running_mean[c] = (1.0f - t.momentum) * t.running_mean[c] + t.momentum * mu;
+    t.running_var[c] = (1.0f - t.momentum) * t.running_var[c] + t.momentum * unbiased;
+  }
+  if (c == 0 && t.num_batches_tracked) *t.num_batches_tracked += 1;
 }
 
 __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -67,12 +94,21 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
 // out = relu(y*scale+shift), written in plain NCDHW and/or in a zero-haloed layout
 // (N,C,D+2,H+2,W+2) that lets the head convolutions run without bounds checks.
 __global__ __launch_bounds__(256) void bn_relu_materialize_kernel(
-    const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ y, const float* __restrict__ scale, const float* __restrict__ shift, msl::BnFold fold,
     float* __restrict__ out_plain, float* __restrict__ out_pad, int C, int D, int H, int W) {
+  __shared__ float s_aff[2];
   const int S = D * H * W;
   const int nc = blockIdx.y;  // n*C + c
   const int c = nc % C;
-  const float sc = scale[c], sh = shift[c];
+  float sc, sh;
+  if (fold.partials) {
+    msl::bn_fold_block(fold, c, 1, &s_aff[0], &s_aff[1]);
+    sc = s_aff[0];
+    sh = s_aff[1];
+  } else {
+    sc = scale[c];
+    sh = shift[c];
+  }
   const size_t base = (size_t)nc * S;
   const int Hp = H + 2, Wp = W + 2;
   const size_t pbase = (size_t)nc * (D + 2) * Hp * Wp;
@@ -264,9 +300,40 @@ int msl_bn_finalize(const double* partials, int num_partials, double count, cons
                     long long* num_batches_tracked, float momentum, float eps, float* scale, float* shift,
                     float* save_mean, float* save_invstd, int C, void* stream) {
   if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(num_partials > 256 ? 256 : 64), 0, (hipStream_t)stream, partials, num_partials,
-                     count, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
-                     shift, save_mean, save_invstd, C);
+  const msl::BnFold f{partials, num_partials, C, count, gamma, beta, eps};
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, f, running_mean, running_var,
+                     num_batches_tracked, momentum, scale, shift, save_mean, save_invstd);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// ---- batched finalize: the host fills a table (one entry per BatchNorm) in HOST memory with msl_bn_finalize_table_set,
+// copies it to the device once, and launches every layer's finalize with one call per step.
+size_t msl_bn_finalize_entry_bytes(void) { return sizeof(BnFinalizeEntry); }
+
+int msl_bn_finalize_table_set(void* host_table, int index, int first_block, const double* partials, int num_partials,
+                              double count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                              float* scale, float* shift, float* save_mean, float* save_invstd, int C) {
+  if (!host_table || index < 0 || C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
+  BnFinalizeEntry& t = reinterpret_cast<BnFinalizeEntry*>(host_table)[index];
+  t.fold = msl::BnFold{partials, num_partials, C, count, gamma, beta, eps};
+  t.running_mean = running_mean;
+  t.running_var = running_var;
+  t.num_batches_tracked = num_batches_tracked;
+  t.momentum = momentum;
+  t.scale = scale;
+  t.shift = shift;
+  t.save_mean = save_mean;
+  t.save_invstd = save_invstd;
+  t.first_block = first_block;
+  return MSL_OK;
+}
+
+int msl_bn_finalize_batch(const void* device_table, int n_entries, int total_channels, void* stream) {
+  if (!device_table || n_entries <= 0 || total_channels <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(total_channels), dim3(64), 0, (hipStream_t)stream,
+                     reinterpret_cast<const BnFinalizeEntry*>(device_table), n_entries);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -285,7 +352,22 @@ int msl_bn_relu_materialize(const float* y, const float* scale, const float* shi
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return MSL_ERR_ARG;
   const int S = D * H * W;
   dim3 grid(min(msl::cdiv(S, 256), 64), N * C);
-  hipLaunchKernelGGL(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift,
+  const msl::BnFold nofold{nullptr, 0, C, 1.0, nullptr, nullptr, 0.f};
+  hipLaunchKernelGGL(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, nofold,
+                     out_plain, out_pad, C, D, H, W);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// same, but the affine is folded from the producer's statistic partials inside the kernel (see common.hpp BnFold)
+int msl_bn_relu_materialize_fold(const float* y, const double* partials, int num_partials, double count,
+                                 const float* gamma, const float* beta, float eps, float* out_plain, float* out_pad,
+                                 int N, int C, int D, int H, int W, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || num_partials <= 0) return MSL_ERR_ARG;
+  const int S = D * H * W;
+  dim3 grid(min(msl::cdiv(S, 256), 64), N * C);
+  const msl::BnFold f{partials, num_partials, C, count, gamma, beta, eps};
+  hipLaunchKernelGGL(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, nullptr, nullptr, f,
                      out_plain, out_pad, C, D, H, W);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

@@ -55,6 +55,90 @@ __device__ __forceinline__ float act(float x, float s, float t) {
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- BatchNorm fold -------------------------------------------------------------------------------------------
+// Turning the fp64 (sum, sumsq) partials of a producer into its per-channel affine is cheap, but as a kernel of its
+// own it sits on the forward dependency chain (15 launches of ~6 us).  So the CONSUMER kernels fold the partials of
+// the channels they read in their prologue, and msl_bn_finalize (same arithmetic, same summation order -> the same
+// bits) runs off the chain on a side stream to update the running statistics and to store the vectors for backward.
+// Canonical order: NP <= 64 -> one thread adds the partials serially; NP > 64 -> 64 lanes take p = lane, lane+64, ...
+// and their sums are combined by the wave_sum tree.
+struct BnFold {
+  const double* partials;  // [2][C][NP]; nullptr = no fold (use the in_scale / in_shift vectors)
+  int NP, C;
+  double count;
+  const float* gamma;
+  const float* beta;
+  float eps;
+};
+
+__device__ __forceinline__ void bn_affine_from_sums(const BnFold& f, int c, double s, double q, float& scale,
+                                                    float& shift, float& mean_o, float& invstd_o, double& var_o) {
+  const double mean = s / f.count;
+  double var = q / f.count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)f.eps);
+  const double sc = (double)f.gamma[c] * invstd;
+  scale = (float)sc;
+  shift = (float)((double)f.beta[c] - mean * sc);
+  mean_o = (float)mean;
+  invstd_o = (float)invstd;
+  var_o = var;
+}
+
+// NP <= 64: call from ONE thread.
+__device__ __forceinline__ void bn_fold_serial(const BnFold& f, int c, float& scale, float& shift, float& mean_o,
+                                               float& invstd_o, double& var_o) {
+  const double* ps = f.partials + (size_t)c * f.NP;
+  const double* pq = f.partials + ((size_t)f.C + c) * f.NP;
+  double s = 0.0, q = 0.0;
+  for (int p = 0; p < f.NP; ++p) {
+    s += ps[p];
+    q += pq[p];
+  }
+  bn_affine_from_sums(f, c, s, q, scale, shift, mean_o, invstd_o, var_o);
+}
+
+// NP > 64: call from all 64 lanes of one wave (same c); results valid in every lane.
+__device__ __forceinline__ void bn_fold_wave(const BnFold& f, int c, float& scale, float& shift, float& mean_o,
+                                             float& invstd_o, double& var_o) {
+  const int lane = threadIdx.x & 63;
+  const double* ps = f.partials + (size_t)c * f.NP;
+  const double* pq = f.partials + ((size_t)f.C + c) * f.NP;
+  double s = 0.0, q = 0.0;
+  for (int p = lane; p < f.NP; p += 64) {
+    s += ps[p];
+    q += pq[p];
+  }
+  s = wave_sum(s);
+  q = wave_sum(q);
+  s = __shfl(s, 0, 64);
+  q = __shfl(q, 0, 64);
+  bn_affine_from_sums(f, c, s, q, scale, shift, mean_o, invstd_o, var_o);
+}
+
+// Fold `nch` channels starting at c0 into LDS arrays (all threads of the workgroup call this; ends with a barrier).
+__device__ __forceinline__ void bn_fold_block(const BnFold& f, int c0, int nch, float* lds_scale, float* lds_shift) {
+  float a, b, m, i;
+  double v;
+  if (f.NP <= 64) {
+    for (int k = threadIdx.x; k < nch; k += blockDim.x) {
+      bn_fold_serial(f, c0 + k, a, b, m, i, v);
+      lds_scale[k] = a;
+      lds_shift[k] = b;
+    }
+  } else {
+    const int wv = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    for (int k = wv; k < nch; k += nw) {
+      bn_fold_wave(f, c0 + k, a, b, m, i, v);
+      if ((threadIdx.x & 63) == 0) {
+        lds_scale[k] = a;
+        lds_shift[k] = b;
+      }
+    }
+  }
+  __syncthreads();
+}
+
 
 // out[i] = sum_k slabs[k * stride + i], k = 0..nslabs-1.  32 outputs x 8 slab groups per workgroup; every thread
 // walks its slabs with independent loads (deep memory-level parallelism), then the 8 group sums are folded

@@ -16,6 +16,7 @@
 // XCD back to back (per-XCD L2).
 #include "common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -115,11 +116,12 @@ __device__ __forceinline__ void emit_bww(float* red, const float* a27, int G, in
 }
 
 template <int STRIDE, int IPT, int LPT, int MODE>
-__global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
+__global__ __launch_bounds__(256, (IPT == 1 ? (MODE == 0 ? 5 : 4) : 2)) void dw_fwd_stream_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int H,
-    int W, int OD, int OH, int OW, int SLAB, int nslabs, int Nbatch) {
+    int W, int OD, int OH, int OW, int SLAB, int nslabs, int Nbatch, msl::BnFold fold) {
   extern __shared__ __align__(16) float lds[];
+  __shared__ float s_aff[2];
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int slab = lb % nslabs;
   const int nc = lb / nslabs;  // n * C + c
@@ -134,8 +136,19 @@ __global__ __launch_bounds__(256, (IPT == 1 ? 4 : 2)) void dw_fwd_stream_kernel(
   const int W4 = W >> 2;
   const int tot4 = H * W4;  // float4 per input plane
 
-  const bool affine = in_scale != nullptr;
-  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+  const bool affine = in_scale != nullptr || fold.partials != nullptr;
+  float sc = 1.f, sh = 0.f;
+  if (fold.partials) {  // fold the producer's BatchNorm statistics here instead of waiting for a finalize launch
+    msl::bn_fold_block(fold, c, 1, &s_aff[0], &s_aff[1]);
+    sc = s_aff[0];
+    sh = s_aff[1];
+  } else if (in_scale) {
+    sc = in_scale[c];
+    sh = in_shift[c];
+  }
+  // workgroup-uniform: keep them in scalar registers whatever path produced them
+  sc = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sc)));
+  sh = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(sh)));
   float wk[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) wk[k] = MODE == 0 ? w[c * 27 + k] : 0.f;  // uniform -> scalar registers
@@ -380,8 +393,10 @@ template <int STRIDE, int MODE>
 __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int H,
-    int W, int OD, int OH, int OW, int G, int SLAB, int nslabs, int Nbatch, int flip, int accumulate) {
+    int W, int OD, int OH, int OW, int G, int SLAB, int nslabs, int Nbatch, int flip, int accumulate,
+    msl::BnFold fold) {
   extern __shared__ __align__(16) float lds[];
+  __shared__ float s_sc[64], s_sh[64];
   const int wbase = flip ? 26 : 0, wsgn = flip ? -1 : 1;  // flipped taps: stride-1 bwd-data == forward with w[26-k]
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int slab = lb % nslabs;
@@ -404,8 +419,16 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
   const int W4 = W >> 2, plane4 = H * W4;
 
   for (int i = threadIdx.x; i < G * CS; i += 256) lds[i] = 0.f;
-  __syncthreads();
-  const bool affine = in_scale != nullptr;
+  const bool affine = in_scale != nullptr || fold.partials != nullptr;
+  if (fold.partials) {
+    msl::bn_fold_block(fold, c0, G, s_sc, s_sh);  // ends with a barrier
+  } else {
+    if (in_scale && threadIdx.x < G) {
+      s_sc[threadIdx.x] = in_scale[c0 + threadIdx.x];
+      s_sh[threadIdx.x] = in_shift[c0 + threadIdx.x];
+    }
+    __syncthreads();
+  }
   const int tot4 = G * NPL * plane4;
   for (int q = threadIdx.x; q < tot4; q += 256) {
     const int g = q / (NPL * plane4);
@@ -416,7 +439,7 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
     const int ih = rem / W4, iw = (rem % W4) * 4;
     float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * C + c0 + g) * D + p) * H * W + (size_t)rem * 4);
     if (affine) {
-      const float sc = in_scale[c0 + g], sh = in_shift[c0 + g];
+      const float sc = s_sc[g], sh = s_sh[g];
       v.x = msl::act(v.x, sc, sh); v.y = msl::act(v.y, sc, sh);
       v.z = msl::act(v.z, sc, sh); v.w = msl::act(v.w, sc, sh);
     }
@@ -502,11 +525,20 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
 __global__ __launch_bounds__(256) void dw_fwd_naive_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ w, float* __restrict__ y, int C, int D, int H, int W, int OD, int OH, int OW,
-    int stride) {
+    int stride, msl::BnFold fold) {
+  __shared__ float s_aff[2];
   const int nc = blockIdx.y, c = nc % C;
   const int OS = OD * OH * OW;
-  const bool affine = in_scale != nullptr;
-  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+  const bool affine = in_scale != nullptr || fold.partials != nullptr;
+  float sc = 1.f, sh = 0.f;
+  if (fold.partials) {
+    msl::bn_fold_block(fold, c, 1, &s_aff[0], &s_aff[1]);
+    sc = s_aff[0];
+    sh = s_aff[1];
+  } else if (in_scale) {
+    sc = in_scale[c];
+    sh = in_shift[c];
+  }
   const float* xc = x + (size_t)nc * D * H * W;
   for (int o = blockIdx.x * 256 + threadIdx.x; o < OS; o += gridDim.x * 256) {
     const int ow = o % OW, oh = (o / OW) % OH, od = o / (OW * OH);
@@ -599,6 +631,10 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
     int slabs = std::max(1, std::min(OD, 1024 / std::max(1, nvol)));
     int SLAB = msl::cdiv(OD, slabs);
     if (SLAB < 4) SLAB = std::min(4, OD);
+    if (const char* e = getenv("MSL_DW_STREAM_SLAB")) {  // tuning knob (tools/bench_dw.py); default: 4 planes
+      const int v = atoi(e);
+      if (v > 0) SLAB = std::min(v, OD);
+    }
     pl.SLAB = SLAB;
     pl.nslabs = msl::cdiv(OD, SLAB);
     pl.lds_bytes = lds;
@@ -619,7 +655,7 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
     return pl;
   }
   int G = std::max(1, 256 / std::max(1, SLAB * Lp));
-  G = pow2_floor(G);
+  G = std::min(pow2_floor(G), 64);
   while (G > 1 && (C % G != 0 || per_ch * G > 60 * 1024)) G /= 2;
   pl.variant = 2;
   pl.G = G;
@@ -655,6 +691,8 @@ int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride) {
 
 // bwd-weight on the LDS-tiled kernels (MODE 1).  Returns MSL_ERR_UNSUPPORTED for shapes on the generic path.
 // partials: fp64 [C*27][NP], NP = msl_dwconv_bwd_weight_num_partials().
+static const msl::BnFold nofold{nullptr, 0, 0, 1.0, nullptr, nullptr, 0.f};
+
 int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in_scale, const float* in_shift,
                                 double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
@@ -672,7 +710,7 @@ int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in
     int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_, 1>, lds);                                                 \
     if (e_) return e_;                                                                                          \
     hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale,   \
-                       in_shift, nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N);        \
+                       in_shift, nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N, nofold); \
   } while (0)
     if (stride == 2) {
       if (pl.ipt == 1 && pl.lpt == 4) MSL_DW_BWW(2, 1, 4);
@@ -687,12 +725,12 @@ int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in
       int e_ = set_lds(dw_fwd_resident_kernel<2, 1>, lds);
       if (e_) return e_;
       hipLaunchKernelGGL((dw_fwd_resident_kernel<2, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
-                         nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
+                         nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, nofold);
     } else {
       int e_ = set_lds(dw_fwd_resident_kernel<1, 1>, lds);
       if (e_) return e_;
       hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
-                         nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
+                         nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, nofold);
     }
   }
   MSL_LAUNCH_CHECK();
@@ -714,14 +752,14 @@ int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in
   int e_ = set_lds(dw_fwd_resident_kernel<1, 0>, pl.lds_bytes);
   if (e_) return e_;
   hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, (hipStream_t)stream, dy,
-                     nullptr, nullptr, w, g_in, nullptr, C, D, H, W, D, H, W, pl.G, pl.SLAB, pl.nslabs, N, 1, accumulate);
+                     nullptr, nullptr, w, g_in, nullptr, C, D, H, W, D, H, W, pl.G, pl.SLAB, pl.nslabs, N, 1, accumulate, nofold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
 
-int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
-                   double* partials, int N, int C, int D, int H, int W, int stride, int force_naive,
-                   void* stream) {
+static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* in_shift, const msl::BnFold& fold,
+                           const float* w, float* y, double* partials, int N, int C, int D, int H, int W, int stride,
+                           int force_naive, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   DwPlan pl = make_plan(N, C, D, H, W, stride);
@@ -733,7 +771,7 @@ int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift,
   if (pl.variant == 0) {
     const int S = OD * OH * OW;
     hipLaunchKernelGGL(dw_fwd_naive_kernel, dim3(std::min(msl::cdiv(S, 256), 256), N * C), dim3(256), 0, st, x,
-                       in_scale, in_shift, w, y, C, D, H, W, OD, OH, OW, stride);
+                       in_scale, in_shift, w, y, C, D, H, W, OD, OH, OW, stride, fold);
     MSL_LAUNCH_CHECK();
     if (partials) {
       const int chunks = msl::cdiv(S, STATS_CHUNK);
@@ -749,7 +787,7 @@ int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift,
     int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_, 0>, pl.lds_bytes);                                          \
     if (e_) return e_;                                                                                         \
     hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x,      \
-                       in_scale, in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N);        \
+                       in_scale, in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N, fold);  \
   } while (0)
     if (stride == 2) {
       if (pl.ipt == 1 && pl.lpt == 4) MSL_DW_STREAM(2, 1, 4);
@@ -764,16 +802,32 @@ int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift,
       int e_ = set_lds(dw_fwd_resident_kernel<2, 0>, pl.lds_bytes);
       if (e_) return e_;
       hipLaunchKernelGGL((dw_fwd_resident_kernel<2, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
-                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
+                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, fold);
     } else {
       int e_ = set_lds(dw_fwd_resident_kernel<1, 0>, pl.lds_bytes);
       if (e_) return e_;
       hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
-                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0);
+                         in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, fold);
     }
   }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
+}
+
+int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
+                   double* partials, int N, int C, int D, int H, int W, int stride, int force_naive,
+                   void* stream) {
+  return dwconv_fwd_impl(x, in_scale, in_shift, nofold, w, y, partials, N, C, D, H, W, stride, force_naive, stream);
+}
+
+// Same, but the input's BatchNorm affine is folded inside the kernel from the producer's statistic partials
+// (in_partials [2][C][in_np], element count in_count, gamma/beta/eps of that BatchNorm): no finalize launch in between.
+int msl_dwconv_fwd_fold(const float* x, const double* in_partials, int in_np, double in_count, const float* gamma,
+                        const float* beta, float eps, const float* w, float* y, double* partials, int N, int C, int D,
+                        int H, int W, int stride, void* stream) {
+  if (!in_partials || in_np <= 0) return MSL_ERR_ARG;
+  const msl::BnFold fold{in_partials, in_np, C, in_count, gamma, beta, eps};
+  return dwconv_fwd_impl(x, nullptr, nullptr, fold, w, y, partials, N, C, D, H, W, stride, 0, stream);
 }
 
 }  // extern "C"

@@ -74,6 +74,17 @@ int msl_event_create(void** out) {
   *out = (void*)ev;
   return MSL_OK;
 }
+int msl_event_create_timed(void** out) {
+  hipEvent_t ev;
+  hipError_t e = hipEventCreate(&ev);
+  if (e != hipSuccess) return (int)e;
+  *out = (void*)ev;
+  return MSL_OK;
+}
+// elapsed milliseconds between two completed timing events
+int msl_event_elapsed_ms(void* start, void* stop, float* out_ms) {
+  return (int)hipEventElapsedTime(out_ms, (hipEvent_t)start, (hipEvent_t)stop);
+}
 int msl_event_destroy(void* ev) { return (int)hipEventDestroy((hipEvent_t)ev); }
 int msl_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEvent_t)ev, (hipStream_t)stream); }
 int msl_stream_wait_event(void* stream, void* ev) {

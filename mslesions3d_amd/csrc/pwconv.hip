@@ -17,6 +17,7 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BM = 64, BN = 128, BK = 32;
+constexpr int FOLD_MAXK = 512;  // input channels whose (scale, shift) are kept in LDS
 constexpr int WS_LD = BK + 1;
 
 template <bool AFFINE, bool STATS, bool TRANS_W>
@@ -24,10 +25,23 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
                                                       const float* __restrict__ in_scale,
                                                       const float* __restrict__ in_shift,
                                                       const float* __restrict__ Wt, float* __restrict__ Y,
-                                                      double* __restrict__ partials, int M, int K, int S) {
+                                                      double* __restrict__ partials, int M, int K, int S,
+                                                      msl::BnFold fold) {
   __shared__ __align__(16) float Xs[BK][BN];
   __shared__ float Ws[BM][WS_LD];
   __shared__ float red[2][2][BM];  // [sum|sumsq][wave column][row]
+  __shared__ float f_sc[AFFINE ? FOLD_MAXK : 1], f_sh[AFFINE ? FOLD_MAXK : 1];
+  if (AFFINE) {
+    if (fold.partials) {
+      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
+    } else {
+      for (int k = threadIdx.x; k < K && k < FOLD_MAXK; k += blockDim.x) {
+        f_sc[k] = in_scale[k];
+        f_sh[k] = in_shift[k];
+      }
+      __syncthreads();
+    }
+  }
   const int n = blockIdx.z, m0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;  // 2 x 2 waves: 32 rows x 64 columns each
@@ -52,7 +66,7 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
         if (col + 3 < S) v.w = src[3];
       }
       if (AFFINE) {
-        const float sc = in_scale[k0 + r], sh = in_shift[k0 + r];
+        const float sc = f_sc[k0 + r], sh = f_sh[k0 + r];
         v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
         v.y = col + 1 < S ? msl::act(v.y, sc, sh) : 0.f;
         v.z = col + 2 < S ? msl::act(v.z, sc, sh) : 0.f;
@@ -138,8 +152,21 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
                                                              const float* __restrict__ in_scale,
                                                              const float* __restrict__ in_shift,
                                                              const float* __restrict__ Wt, float* __restrict__ Y,
-                                                             double* __restrict__ partials, int M, int K, int S) {
+                                                             double* __restrict__ partials, int M, int K, int S,
+                                                             msl::BnFold fold) {
   extern __shared__ __align__(16) float lds[];  // NW * KS_WAVE_LDS floats
+  __shared__ float f_sc[AFFINE ? FOLD_MAXK : 1], f_sh[AFFINE ? FOLD_MAXK : 1];
+  if (AFFINE) {
+    if (fold.partials) {
+      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
+    } else {
+      for (int k = threadIdx.x; k < K && k < FOLD_MAXK; k += blockDim.x) {
+        f_sc[k] = in_scale[k];
+        f_sh[k] = in_shift[k];
+      }
+      __syncthreads();
+    }
+  }
   const int n = blockIdx.z, m0 = blockIdx.y * KS_BM, s0 = blockIdx.x * KS_BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float* Xs = lds + wv * KS_WAVE_LDS;   // [BK][KS_BN]
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
         if (col + 3 < S) v.w = src[3];
       }
       if (AFFINE) {
-        const float sc = in_scale[k0 + r], sh = in_shift[k0 + r];
+        const float sc = f_sc[k0 + r], sh = f_sh[k0 + r];
         v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
         v.y = col + 1 < S ? msl::act(v.y, sc, sh) : 0.f;
         v.z = col + 2 < S ? msl::act(v.z, sc, sh) : 0.f;
@@ -429,9 +456,12 @@ int msl_pwconv_fwd_num_partials(int N, int Cin, int Cout, int S) {
 }
 
 // z (N,Cin,S) raw + input affine -> y (N,Cout,S) raw + stat partials [2][Cout][NP]
-int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
-                   double* partials, int N, int Cin, int Cout, int S, void* stream) {
+static const msl::BnFold pw_nofold{nullptr, 0, 0, 1.0, nullptr, nullptr, 0.f};
+
+static int pwconv_fwd_impl(const float* z, const float* in_scale, const float* in_shift, const msl::BnFold& fold,
+                           const float* w, float* y, double* partials, int N, int Cin, int Cout, int S, void* stream) {
   if (N <= 0 || S <= 0 || Cin % BK != 0 || Cout % 4 != 0) return MSL_ERR_ARG;
+  if ((in_scale || fold.partials) && Cin > FOLD_MAXK) return MSL_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (use_ksplit(Cin, Cout, S, N)) {
     dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cout, KS_BM), N);
@@ -443,13 +473,13 @@ int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift,
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                  \
       if (e_ != hipSuccess) return (int)e_;                                                                        \
       hipLaunchKernelGGL((pw_gemm_ksplit_kernel<A_, S_, T_, 8>), g2, dim3(512), lds_, st, X_, in_scale, in_shift,  \
-                         Wp_, Y_, P_, M_, K_, S);                                                                  \
+                         Wp_, Y_, P_, M_, K_, S, fold);                                                            \
     } else {                                                                                                       \
       hipLaunchKernelGGL((pw_gemm_ksplit_kernel<A_, S_, T_, 4>), g2, dim3(256),                                    \
-                         (size_t)4 * KS_WAVE_LDS * sizeof(float), st, X_, in_scale, in_shift, Wp_, Y_, P_, M_, K_, S); \
+                         (size_t)4 * KS_WAVE_LDS * sizeof(float), st, X_, in_scale, in_shift, Wp_, Y_, P_, M_, K_, S, fold); \
     }                                                                                                              \
   } while (0)
-    if (in_scale) {
+    if (in_scale || fold.partials) {
       if (partials) MSL_KS(true, true, false, z, w, y, partials, Cout, Cin);
       else MSL_KS(true, false, false, z, w, y, partials, Cout, Cin);
     } else {
@@ -460,15 +490,29 @@ int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift,
     return MSL_OK;
   }
   dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cout, BM), N);
-  if (in_scale) {
-    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<true, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
-    else hipLaunchKernelGGL((pw_gemm_kernel<true, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+  if (in_scale || fold.partials) {
+    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<true, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
+    else hipLaunchKernelGGL((pw_gemm_kernel<true, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
   } else {
-    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<false, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
-    else hipLaunchKernelGGL((pw_gemm_kernel<false, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S);
+    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<false, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
+    else hipLaunchKernelGGL((pw_gemm_kernel<false, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
   }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
+}
+
+int msl_pwconv_fwd(const float* z, const float* in_scale, const float* in_shift, const float* w, float* y,
+                   double* partials, int N, int Cin, int Cout, int S, void* stream) {
+  return pwconv_fwd_impl(z, in_scale, in_shift, pw_nofold, w, y, partials, N, Cin, Cout, S, stream);
+}
+
+// Same, with the input's BatchNorm affine folded in the kernel prologue from the producer's partials.
+int msl_pwconv_fwd_fold(const float* z, const double* in_partials, int in_np, double in_count, const float* gamma,
+                        const float* beta, float eps, const float* w, float* y, double* partials, int N, int Cin,
+                        int Cout, int S, void* stream) {
+  if (!in_partials || in_np <= 0) return MSL_ERR_ARG;
+  const msl::BnFold fold{in_partials, in_np, Cin, in_count, gamma, beta, eps};
+  return pwconv_fwd_impl(z, nullptr, nullptr, fold, w, y, partials, N, Cin, Cout, S, stream);
 }
 
 // dy (N,Cout,S) -> g_in (N,Cin,S) = W^T . dy
@@ -480,13 +524,14 @@ int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
     hipStream_t st = (hipStream_t)stream;
     const float *in_scale = nullptr, *in_shift = nullptr;
     double* nopart = nullptr;
+    const msl::BnFold fold = pw_nofold;
     MSL_KS(false, false, true, dy, w, g_in, nopart, Cin, Cout);
     MSL_LAUNCH_CHECK();
     return MSL_OK;
   }
   dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cin, BM), N);
   hipLaunchKernelGGL((pw_gemm_kernel<false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
-                     nullptr, w, g_in, nullptr, Cin, Cout, S);
+                     nullptr, w, g_in, nullptr, Cin, Cout, S, pw_nofold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

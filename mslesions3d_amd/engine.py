@@ -131,6 +131,20 @@ class Plan:
             if need_grad:
                 part_elems = max(part_elems, 2 * sp["cout"] * L.msl_bn_relu_bwd_num_partials(N, S))
         self.partials = torch.empty(max(part_elems, 1), dtype=torch.float64, device=device)
+        # one statistics buffer per BatchNorm: the consumer folds them in its prologue while the finalize kernel
+        # (running stats + vectors for backward) reads them on a side stream
+        f64 = dict(dtype=torch.float64, device=device)
+        self.np_y, self.np_z, self.part_y, self.part_z = [], [None], [], [None]
+        for i, sp in enumerate(specs):
+            D, H, W = self.dims[i]
+            if i == 0:
+                self.np_y.append(L.msl_stem_conv_fwd_num_partials(N, D, H, W))
+            else:
+                pd, ph, pw = self.dims[i - 1]
+                self.np_z.append(L.msl_dwconv_fwd_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]))
+                self.part_z.append(torch.empty(2 * sp["cin"] * self.np_z[i], **f64))
+                self.np_y.append(L.msl_pwconv_fwd_num_partials(N, sp["cin"], sp["cout"], D * H * W))
+            self.part_y.append(torch.empty(2 * sp["cout"] * self.np_y[i], **f64))
 
         # heads
         self.feat_ids = list(m.aspect_ratios.keys())
@@ -184,6 +198,10 @@ class Engine:
     def __init__(self, model):
         self.model = model
         self.multi_stream = True
+        # Folding the BatchNorm statistics inside the consumer kernels (csrc/common.hpp BnFold) removes the 15
+        # finalize launches from the forward chain, but every workgroup then re-reads the partials: measured on
+        # MI355X it costs each consumer what the launch saved (depthwise block 1: 40 -> 49 us) — off by default.
+        self.fold_bn = False
         self.side = {}
         self.arena = None
         self.plans = {}
@@ -261,7 +279,9 @@ class Engine:
     def stop_profile(self):
         """-> {tag: [ms, ...]} (synchronises)."""
         torch.cuda.synchronize()
-        out = {t: [a.elapsed_time(b) for a, b in ev] for t, ev in (self.prof or {}).items()}
+        out = {}
+        for t, evs in (self.prof or {}).items():
+            out[t] = [(_lib.elapsed_ms(e[1], e[2]) if e[0] == "c" else e[0].elapsed_time(e[1])) for e in evs]
         self.prof = None
         return out
 
@@ -311,55 +331,83 @@ class Engine:
         N = pl.N
         feats = m.base.features
         specs = self.layer_specs
-        part = pl.partials
-        pp = ptr(part) if training else None
         _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
+
+        fold = training and self.fold_bn
+        deferred = []
+        bn_layers = []  # (bn module, vector buffer, partials, NP, element count) of every BatchNorm, in order
+
+        def finalize_later(bn, vec, part, NP, count, name):
+            """BatchNorm finalize (running stats + vectors for backward): all layers in ONE launch after the last
+            block — nothing in the forward pass reads its outputs."""
+            bn_layers.append((bn, vec, part, NP, count))
+
+        def flush():
+            nonlocal deferred
+            for fn in deferred:
+                fn()
+            deferred = []
 
         # stem (features[0] = Conv3d + BN + ReLU)
         D, H, W = pl.in_dims
         sd, sh, sw = specs[0]["stride"]
-        self._k("stem_fwd", "msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), pp, N, specs[0]["cin"], D, H, W,
-                  sd, sh, sw, st)
+        self._k("stem_fwd", "msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]),
+                ptr(pl.part_y[0]) if training else None, N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         od, oh, ow = pl.dims[0]
-        self._bn_fwd(feats[0][1], pl.bn_y[0], part, L.msl_stem_conv_fwd_num_partials(N, od, oh, ow),
-                     N * od * oh * ow, training, st)
+        if fold:
+            finalize_later(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], N * od * oh * ow, "stat_y0")
+        else:
+            self._bn_fwd(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], N * od * oh * ow, training, st)
         out_feats = {}
-        deferred = []
         for i in range(1, len(specs)):
             sp, blk = specs[i], feats[i]
             pd, ph, pw = pl.dims[i - 1]
             D, H, W = pl.dims[i]
             S = D * H * W
             s = sp["stride"][0]
-            self._k(f"dw_fwd{i}", "msl_dwconv_fwd", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
-                      ptr(blk.conv1.weight), ptr(pl.z[i]), pp, N, sp["cin"], pd, ph, pw, s, 0, st)
-            self._bn_fwd(blk.bn1, pl.bn_z[i], part, L.msl_dwconv_fwd_num_partials(N, sp["cin"], pd, ph, pw, s),
-                         N * S, training, st)
-            self._k(f"pw_fwd{i}", "msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(blk.conv2.weight),
-                      ptr(pl.y[i]), pp, N, sp["cin"], sp["cout"], S, st)
-            self._bn_fwd(blk.bn2, pl.bn_y[i], part, L.msl_pwconv_fwd_num_partials(N, sp["cin"], sp["cout"], S), N * S, training, st)
+            bn_prev = feats[0][1] if i == 1 else feats[i - 1].bn2
+            if fold:
+                self._k(f"dw_fwd{i}", "msl_dwconv_fwd_fold", ptr(pl.y[i - 1]), ptr(pl.part_y[i - 1]), pl.np_y[i - 1],
+                        float(N * pd * ph * pw), ptr(bn_prev.weight), ptr(bn_prev.bias), bn_prev.eps, ptr(blk.conv1.weight),
+                        ptr(pl.z[i]), ptr(pl.part_z[i]), N, sp["cin"], pd, ph, pw, s, st)
+                flush()
+                finalize_later(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, f"stat_z{i}")
+                self._k(f"pw_fwd{i}", "msl_pwconv_fwd_fold", ptr(pl.z[i]), ptr(pl.part_z[i]), pl.np_z[i], float(N * S),
+                        ptr(blk.bn1.weight), ptr(blk.bn1.bias), blk.bn1.eps, ptr(blk.conv2.weight), ptr(pl.y[i]),
+                        ptr(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
+                flush()
+                finalize_later(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, f"stat_y{i}")
+            else:
+                self._k(f"dw_fwd{i}", "msl_dwconv_fwd", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
+                        ptr(blk.conv1.weight), ptr(pl.z[i]), ptr(pl.part_z[i]) if training else None, N, sp["cin"], pd, ph,
+                        pw, s, 0, st)
+                self._bn_fwd(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, training, st)
+                self._k(f"pw_fwd{i}", "msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
+                        ptr(blk.conv2.weight), ptr(pl.y[i]), ptr(pl.part_y[i]) if training else None, N, sp["cin"],
+                        sp["cout"], S, st)
+                self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, training, st)
             if i in pl.fpad:
                 plain = None
                 if want_features:
                     plain = torch.empty((N, sp["cout"], D, H, W), dtype=torch.float32, device=x.device)
                     out_feats[i] = plain
-                self._k(f"materialize{i}", "msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]), ptr(pl.bn_y[i][1]), ptr(plain),
-                          ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
+                if fold:
+                    self._k(f"materialize{i}", "msl_bn_relu_materialize_fold", ptr(pl.y[i]), ptr(pl.part_y[i]), pl.np_y[i],
+                            float(N * S), ptr(blk.bn2.weight), ptr(blk.bn2.bias), blk.bn2.eps, ptr(plain), ptr(pl.fpad[i]),
+                            N, sp["cout"], D, H, W, st)
+                else:
+                    self._k(f"materialize{i}", "msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
+                            ptr(pl.bn_y[i][1]), ptr(plain), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
                 # this scale's head convolution only needs the feature map: run it beside the remaining blocks
                 last = i == len(specs) - 1
                 if self.multi_stream and not last:
-                    # record now, launch the head after the NEXT block's kernels have been enqueued (host order
-                    # decides which queue starves; the backbone chain must never wait for the host)
                     ev = self._record(pl, f"fwd_feat{i}", st)
                     deferred.append(lambda ev=ev, i=i: (self._wait(stH, ev), self._head_forward(pl, i, stH)))
                 else:
                     self._head_forward(pl, i, st)
-            elif deferred:
-                for fn in deferred:
-                    fn()
-                deferred = []
-        for fn in deferred:
-            fn()
+        flush()
+        if fold:
+            self._finalize_all(pl, bn_layers, st)
         if self.multi_stream:
             self._fork(pl, "fwd_heads_done", stH, st)
         _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
@@ -367,6 +415,28 @@ class Engine:
         if want_features:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores
+
+    def _finalize_all(self, pl, bn_layers, st):
+        """One launch for the running statistics and backward vectors of every BatchNorm (table built once per plan)."""
+        import ctypes
+        L = _lib.load()
+        key = tuple((ptr(bn.weight), ptr(bn.running_mean)) for bn, *_ in bn_layers)
+        if getattr(pl, "bn_table_key", None) != key:
+            esz = L.msl_bn_finalize_entry_bytes()
+            host = (ctypes.c_ubyte * (esz * len(bn_layers)))()
+            first = 0
+            for k, (bn, vec, part, NP, count) in enumerate(bn_layers):
+                C = vec.shape[1]
+                mom = 0.1 if bn.momentum is None else bn.momentum
+                _lib.check(L.msl_bn_finalize_table_set(ctypes.addressof(host), k, first, ptr(part), NP, float(count),
+                                                       ptr(bn.weight), ptr(bn.bias), ptr(bn.running_mean),
+                                                       ptr(bn.running_var), ptr(bn.num_batches_tracked), mom, bn.eps,
+                                                       ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C),
+                           "msl_bn_finalize_table_set")
+                first += C
+            pl.bn_table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(vec.device)
+            pl.bn_table_key, pl.bn_table_n, pl.bn_table_channels = key, len(bn_layers), first
+        _lib.call("msl_bn_finalize_batch", ptr(pl.bn_table), pl.bn_table_n, pl.bn_table_channels, st, tag="bn_finalize_all")
 
     def _head_forward(self, pl, f, st):
         m = self.model
@@ -482,7 +552,6 @@ class Engine:
             # weight gradients (wgrad stream, waiting on events recorded in the chain) afterwards: the chain is made of
             # ~10 us kernels, so any launch queued in front of its next link shows up as idle time.
             self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st)
-            ev_dy = self._record(pl, f"dy{i}", st) if ms else None
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
                     sp["cout"], S, st)
             self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
@@ -492,13 +561,11 @@ class Engine:
                 self._wait(st, pl.events[f"head_done{i - 1}"])
             self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
                     sp["cin"], pd, ph, pw, s, accumulate, st)
-            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dy=ev_dy, ev_dz=ev_dz):
-                if ms:
-                    self._wait(stW, ev_dy)
+            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz):
+                if ms:  # one event per layer: both weight gradients start once dL/dz_i is final
+                    self._wait(stW, ev_dz)
                 self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
                         ptr(pl.bn_z[i][1]), ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, stW)
-                if ms:
-                    self._wait(stW, ev_dz)
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
                         ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w if ms else pl.partials),
                         N, sp["cin"], pd, ph, pw, s, stW)

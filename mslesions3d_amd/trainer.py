@@ -108,7 +108,7 @@ class FusedTrainer:
                     segs = entry.setdefault("native_timed", {}).get(tags)
                     if segs is None:
                         segs = entry["native_timed"][tags] = _lib.compile_program(prog, tags)
-                    _lib.replay_native(segs, eng.prof, lambda: torch.cuda.Event(enable_timing=True))
+                    _lib.replay_native(segs, eng.prof)
                 elif graph_ok:
                     if entry["graph"] is None:
                         entry["graph"] = _lib.capture_graph(prog, stream)

@@ -241,6 +241,27 @@ def test_replayed_launch_program_equals_eager_steps():
     assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
 
 
+def test_in_kernel_bn_fold_is_bit_identical():
+    """Engine.fold_bn (consumers fold the BatchNorm partials in their prologue, one batched finalize) must give the
+    same bits as the default per-layer finalize launches: same arithmetic, same summation order."""
+    size, n = (64, 64, 64), 2
+    x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, n, size)
+    outs = []
+    for fold in (False, True):
+        m = hip_model(1, size)
+        m._engine.fold_bn = fold
+        m.train()
+        l, s = m(x)
+        c, lc = m.loss_fn(l, s, [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels])
+        (c + lc).backward()
+        sd = m.state_dict()
+        outs.append((l.clone(), s.clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]),
+                     sd["base.features.5.bn2.running_var"].clone(), sd["base.features.0.1.running_mean"].clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
 def test_determinism_run_to_run():
     size, n = (64, 64, 64), 2
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
