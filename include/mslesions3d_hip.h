@@ -68,6 +68,11 @@ size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin);
 int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D,
                              int H, int W, int sd, int sh, int sw, void* stream);
 
+/* same, with the BatchNorm+ReLU backward of the stem applied while loading: g = dL/d relu(bn(y)), bn_vec (6,32) */
+int msl_stem_conv_bwd_weight_bnapply(const float* g, const float* yraw, const float* bn_vec, const float* x, float* dw,
+                                     float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
+                                     void* stream);
+
 /* ---- depthwise Conv3d(C,C,k3,stride s,p1,groups=C) : Block.conv1, mobilenet.py:38,44 ---------------------- */
 int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride); /* 0 naive, 1 stream, 2 resident */
@@ -86,6 +91,12 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
 int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in_scale, const float* in_shift,
                                 double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
 int msl_dwconv_bwd_weight_tiled_num_partials(int N, int C, int D, int H, int W, int stride);
+/* stride-2 bwd-data that also emits the BatchNorm-backward partials of the layer it feeds (fp64 [2][C][NP]) */
+int msl_dwconv_bwd_data_bnreduce_num_partials(int N, int C, int D, int H, int W);
+int msl_dwconv_bwd_data_bnreduce(const float* dy, const float* w, float* g_in, const float* y_prev,
+                                 const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                 const float* bn_invstd, double* partials, int N, int C, int D, int H, int W, int stride,
+                                 int accumulate, void* stream);
 int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream);

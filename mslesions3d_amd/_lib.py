@@ -30,12 +30,15 @@ _SIGNATURES = {
     "msl_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_stem_conv_bwd_weight_workspace_bytes": (_Z, [_I]),
     "msl_stem_conv_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_stem_conv_bwd_weight_bnapply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd_variant": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_s1_bwd_data_resident": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_data_bnreduce_num_partials": (_I, [_I, _I, _I, _I, _I]),
+    "msl_dwconv_bwd_data_bnreduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_tiled": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_tiled_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_bwd_weight_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),

@@ -120,14 +120,28 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
 // (iw0 .. iw0+3).  The parity of every coordinate is then static: the 16 outputs read the same 12 dy values and
 // every weight index is a compile-time constant (54 FMAs, no tap selection), and the patch is written as four
 // 16-B stores.  This is the kernel that writes the 134 MB stem-gradient tensor.
+// REDUCE: the tensor written here is dL/d relu(bn(y_prev)); its BatchNorm backward needs sum(gm) and sum(gm * xhat)
+// per channel.  The kernel already holds every g value in registers, so it reads y_prev at the same 16 positions
+// and emits the fp64 partials itself: the separate reduce pass (a second read of the 134 MB gradient at block 1)
+// disappears.
+template <bool REDUCE>
 __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* __restrict__ dy,
                                                                    const float* __restrict__ w,
                                                                    float* __restrict__ g_in, int C, int D, int H, int W,
-                                                                   int OD, int OH, int OW, int accumulate) {
+                                                                   int OD, int OH, int OW, int accumulate,
+                                                                   const float* __restrict__ y_prev,
+                                                                   const float* __restrict__ bn_scale,
+                                                                   const float* __restrict__ bn_shift,
+                                                                   const float* __restrict__ bn_mean,
+                                                                   const float* __restrict__ bn_invstd,
+                                                                   double* __restrict__ partials) {
+  __shared__ double scratch[8];
   const int nc = blockIdx.y, c = nc % C;
   const int W4 = W >> 2, H2 = (H + 1) >> 1, D2 = (D + 1) >> 1;
-  const int q = blockIdx.x * 256 + threadIdx.x;
-  if (q >= D2 * H2 * W4) return;
+  const int q0 = blockIdx.x * 256 + threadIdx.x;
+  const bool live = q0 < D2 * H2 * W4;
+  if (!REDUCE && !live) return;
+  const int q = live ? q0 : 0;
   const int cw = q % W4, b = (q / W4) % H2, a = q / (W4 * H2);
   const int iw0 = cw * 4, c2 = cw * 2;
   float wk[27];
@@ -168,21 +182,48 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
       g[pd][ph][0] = o0; g[pd][ph][1] = o1; g[pd][ph][2] = o2; g[pd][ph][3] = o3;
     }
   float* base = g_in + (size_t)nc * D * H * W;
+  float s1 = 0.f, s2 = 0.f;
+  float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
+  if (REDUCE) {
+    sc = bn_scale[c]; sh = bn_shift[c]; mu = bn_mean[c]; is = bn_invstd[c];
+  }
 #pragma unroll
   for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
       const int id = 2 * a + pd, ih = 2 * b + ph;
-      if (id < D && ih < H) {
-        float* dst = base + ((size_t)id * H + ih) * W + iw0;
+      if (live && id < D && ih < H) {
+        const size_t off = (size_t)nc * D * H * W + ((size_t)id * H + ih) * W + iw0;
+        float* dst = g_in + off;
         float4 v = make_float4(g[pd][ph][0], g[pd][ph][1], g[pd][ph][2], g[pd][ph][3]);
         if (accumulate) {
           const float4 old = *reinterpret_cast<const float4*>(dst);
           v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
         }
         *reinterpret_cast<float4*>(dst) = v;
+        if (REDUCE) {
+          const float4 yv = *reinterpret_cast<const float4*>(y_prev + off);
+          const float ga[4] = {v.x, v.y, v.z, v.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const float gm = fmaf(ya[k], sc, sh) > 0.f ? ga[k] : 0.f;
+            s1 += gm;
+            s2 += gm * ((ya[k] - mu) * is);
+          }
+        }
       }
     }
+  (void)base;
+  if (REDUCE) {
+    const int NP = (gridDim.y / C) * gridDim.x, p = (nc / C) * gridDim.x + blockIdx.x;
+    const double t1 = msl::block_sum((double)s1, scratch);
+    __syncthreads();
+    const double t2 = msl::block_sum((double)s2, scratch);
+    if (threadIdx.x == 0) {
+      partials[(size_t)c * NP + p] = t1;
+      partials[((size_t)C + c) * NP + p] = t2;
+    }
+  }
 }
 
 // generic fallback: one input voxel per thread, any shape
@@ -296,7 +337,8 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
   if (W % 4 == 0) {
     if (stride == 2) {
       dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
-      hipLaunchKernelGGL(dw_bwd_data_s2_patch_kernel, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
+      hipLaunchKernelGGL(dw_bwd_data_s2_patch_kernel<false>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW,
+                         accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     } else {
       dim3 grid(msl::cdiv(D * H * (W / 4), 256), N * C);
       hipLaunchKernelGGL(dw_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
@@ -305,6 +347,28 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
     dim3 grid(std::min(msl::cdiv(D * H * W, 256), 256), N * C);
     hipLaunchKernelGGL(dw_bwd_data_naive_kernel, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, stride, accumulate);
   }
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// Stride-2 bwd-data that also emits the BatchNorm-backward partials (sum gm, sum gm*xhat; fp64 [2][C][NP]) of the
+// layer whose activation gradient it writes (y_prev = that layer's raw conv output, vec = its folded BatchNorm).
+// -2 unless stride == 2 and W % 4 == 0.
+int msl_dwconv_bwd_data_bnreduce_num_partials(int N, int C, int D, int H, int W) {
+  if (W % 4 != 0) return -1;
+  return N * msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256);
+}
+
+int msl_dwconv_bwd_data_bnreduce(const float* dy, const float* w, float* g_in, const float* y_prev,
+                                 const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                 const float* bn_invstd, double* partials, int N, int C, int D, int H, int W, int stride,
+                                 int accumulate, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return MSL_ERR_ARG;
+  if (stride != 2 || W % 4 != 0) return MSL_ERR_UNSUPPORTED;
+  const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
+  hipLaunchKernelGGL(dw_bwd_data_s2_patch_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, w, g_in, C, D, H, W,
+                     OD, OH, OW, accumulate, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, partials);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -110,11 +110,16 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SB_DY_LD = 65;     // dy tile pitch
 constexpr int SB_ROW_LD = 131;   // input row pitch (2*64 + 1 = 129 needed; 131 % 32 == 3)
 
-template <int CIN>
+// APPLY: `dy` holds dL/d relu(bn(y)) (not yet through the BatchNorm backward); the kernel reads y as well and
+// applies  dL/dy = scale * (gm - c1 - xhat * c2)  while staging the tile, so the 402 MB apply pass over the stem
+// gradient never runs.  bnv = [scale, shift, mean, invstd, c1, c2] x 32 channels.
+template <int CIN, bool APPLY>
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               float* __restrict__ slabs, int N, int D, int H, int W,
                                                               int OD, int OH, int OW, int sd, int sh, int sw,
-                                                              int chunks_per_row, int total_chunks, int iters) {
+                                                              int chunks_per_row, int total_chunks, int iters,
+                                                              const float* __restrict__ yraw,
+                                                              const float* __restrict__ bnv) {
   constexpr int NT = (CIN * 27 + 31) / 32;
   constexpr int WAVE_LDS = 32 * SB_DY_LD + CIN * 9 * SB_ROW_LD;
   extern __shared__ __align__(16) float lds[];
@@ -155,9 +160,20 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     // store to LDS: a load->store->load chain would expose the full memory latency 59 times per chunk.
     float dreg[32];
     {
-      const float* src = dy + (size_t)n * 32 * OS + ((size_t)od * OH + oh) * OW + ow0 + lane;
+      const size_t off = (size_t)n * 32 * OS + ((size_t)od * OH + oh) * OW + ow0 + lane;
+      const float* src = dy + off;
 #pragma unroll
       for (int co = 0; co < 32; ++co) dreg[co] = lane < npos ? src[(size_t)co * OS] : 0.f;
+      if (APPLY) {
+        const float* ysrc = yraw + off;
+#pragma unroll
+        for (int co = 0; co < 32; ++co) {
+          const float yv = lane < npos ? ysrc[(size_t)co * OS] : 0.f;
+          const float sc = bnv[co], sf = bnv[32 + co], mu = bnv[64 + co], is = bnv[96 + co];
+          const float gm = fmaf(yv, sc, sf) > 0.f ? dreg[co] : 0.f;
+          dreg[co] = lane < npos ? sc * (gm - bnv[128 + co] - ((yv - mu) * is) * bnv[160 + co]) : 0.f;
+        }
+      }
     }
     float xreg[CIN * 9][3];
     {
@@ -274,8 +290,25 @@ size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin) {
 }
 
 // dw (32,Cin,3,3,3) = correlation of dy (N,32,OD,OH,OW) with x (N,Cin,D,H,W)
+static int stem_bww_impl(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
+                         int sd, int sh, int sw, const float* yraw, const float* bnv, void* stream);
+
 int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D,
                              int H, int W, int sd, int sh, int sw, void* stream) {
+  return stem_bww_impl(dy, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, nullptr, nullptr, stream);
+}
+
+// g = dL/d relu(bn(y)): BatchNorm backward applied on load.  bn_vec = (6, 32) fp32 rows [scale, shift, mean, invstd,
+// c1 = dbeta/n, c2 = dgamma/n] as produced by msl_bn_finalize + msl_bn_bwd_finalize.
+int msl_stem_conv_bwd_weight_bnapply(const float* g, const float* yraw, const float* bn_vec, const float* x, float* dw,
+                                     float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
+                                     void* stream) {
+  if (!yraw || !bn_vec) return MSL_ERR_ARG;
+  return stem_bww_impl(g, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, yraw, bn_vec, stream);
+}
+
+static int stem_bww_impl(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
+                         int sd, int sh, int sw, const float* yraw, const float* bnv, void* stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || sd < 1 || sd > 2 || sh < 1 || sh > 2 || sw < 1 || sw > 2)
     return MSL_ERR_ARG;
   const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
@@ -286,15 +319,20 @@ int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* 
   hipStream_t st = (hipStream_t)stream;
   const int NT = (Cin * 27 + 31) / 32;
   const size_t lds = (size_t)4 * (32 * SB_DY_LD + Cin * 9 * SB_ROW_LD) * sizeof(float);
-#define MSL_STEM_BW(CI)                                                                                              \
+#define MSL_STEM_BW1(CI, AP)                                                                                         \
   do {                                                                                                               \
     if (lds > 64 * 1024) {                                                                                           \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_weight_kernel<CI>),                 \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_weight_kernel<CI, AP>),             \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e_ != hipSuccess) return (int)e_;                                                                          \
     }                                                                                                                \
-    hipLaunchKernelGGL(stem_bwd_weight_kernel<CI>, dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, D, H, W,  \
-                       OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters);                                 \
+    hipLaunchKernelGGL((stem_bwd_weight_kernel<CI, AP>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, D,  \
+                       H, W, OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters, yraw, bnv);                \
+  } while (0)
+#define MSL_STEM_BW(CI)            \
+  do {                             \
+    if (yraw) MSL_STEM_BW1(CI, true); \
+    else MSL_STEM_BW1(CI, false);  \
   } while (0)
   switch (Cin) {
     case 1: MSL_STEM_BW(1); break;
@@ -304,6 +342,7 @@ int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* 
     default: return MSL_ERR_UNSUPPORTED;
   }
 #undef MSL_STEM_BW
+#undef MSL_STEM_BW1
   MSL_LAUNCH_CHECK();
   const int K = Cin * 27;
   hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw, K,

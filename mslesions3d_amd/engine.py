@@ -127,7 +127,8 @@ class Plan:
                 if need_grad:
                     part_elems = max(part_elems,
                                      sp["cin"] * 27 * L.msl_dwconv_bwd_weight_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]),
-                                     2 * sp["cin"] * L.msl_bn_relu_bwd_num_partials(N, S))
+                                     2 * sp["cin"] * L.msl_bn_relu_bwd_num_partials(N, S),
+                                     2 * sp["cin"] * max(L.msl_dwconv_bwd_data_bnreduce_num_partials(N, sp["cin"], pd, ph, pw), 0))
             if need_grad:
                 part_elems = max(part_elems, 2 * sp["cout"] * L.msl_bn_relu_bwd_num_partials(N, S))
         self.partials = torch.empty(max(part_elems, 1), dtype=torch.float64, device=device)
@@ -450,10 +451,19 @@ class Engine:
                 ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
 
     # ------------------------------------------------------------------------------------------------
-    def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st):
-        """In place: g (= dL/d relu(bn(y))) becomes dL/dy; writes dgamma/dbeta into the gradient arena."""
+    def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st, pre_np=None, apply=True):
+        """In place: g (= dL/d relu(bn(y))) becomes dL/dy; writes dgamma/dbeta into the gradient arena.
+        ``pre_np``: the producer of g already emitted the reduce partials (pl.partials, that many per channel);
+        ``apply=False``: the consumer applies the BatchNorm backward itself while loading (only c1/c2 are produced)."""
         L = _lib.load()
         gv = self.arena.grad_views
+        if pre_np is not None:
+            _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), pre_np, float(count), ptr(gv[bn_name + ".weight"]),
+                      ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
+            if apply:
+                self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+                        ptr(vec[3]), ptr(vec[4]), ptr(vec[5]), ptr(g), N, C, S, st)
+            return
         if N * S <= 65536:  # small per-channel data: reduce + finalize + apply in one launch
             self._k("bn_bwd_fused:" + bn_name, "msl_bn_relu_bwd_fused", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]),
                     ptr(vec[2]), ptr(vec[3]), ptr(gv[bn_name + ".weight"]), ptr(gv[bn_name + ".bias"]), ptr(g), N, C, S, st)
@@ -521,6 +531,8 @@ class Engine:
         side_feats = [f for f in pl.feat_ids if f != last] if ms else []
         if side_feats:
             self._fork(pl, "bwd_loss_ready", st, stH)
+        L = _lib.load()
+        pre_np = None  # set when the producer of the next activation gradient also produced its BatchNorm partials
         pending = []  # side-stream launches, issued one layer late so that the chain's launches always go first
         for f in pl.feat_ids:  # the chain's own scale first: its data gradient starts the backward chain
             if f not in side_feats:
@@ -551,7 +563,8 @@ class Engine:
             # then the depthwise gradients.  The host enqueues the dependency chain (main stream) FIRST and the two
             # weight gradients (wgrad stream, waiting on events recorded in the chain) afterwards: the chain is made of
             # ~10 us kernels, so any launch queued in front of its next link shows up as idle time.
-            self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st)
+            self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st, pre_np=pre_np)
+            pre_np = None
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
                     sp["cout"], S, st)
             self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
@@ -559,8 +572,18 @@ class Engine:
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
             if accumulate and (i - 1) in side_feats:
                 self._wait(st, pl.events[f"head_done{i - 1}"])
-            self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
-                    sp["cin"], pd, ph, pw, s, accumulate, st)
+            # big producer layers: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
+            Sp = pd * ph * pw
+            np_red = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, sp["cin"], pd, ph, pw) if (s == 2 and N * Sp > 65536) else -1
+            if np_red > 0 and 2 * sp["cin"] * np_red <= pl.partials.numel():
+                vp = pl.bn_y[i - 1]
+                self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bnreduce", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight),
+                        ptr(pl.g_y[i - 1]), ptr(pl.y[i - 1]), ptr(vp[0]), ptr(vp[1]), ptr(vp[2]), ptr(vp[3]), ptr(pl.partials),
+                        N, sp["cin"], pd, ph, pw, s, accumulate, st)
+                pre_np = np_red
+            else:
+                self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
+                        N, sp["cin"], pd, ph, pw, s, accumulate, st)
             def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz):
                 if ms:  # one event per layer: both weight gradients start once dL/dz_i is final
                     self._wait(stW, ev_dz)
@@ -584,11 +607,20 @@ class Engine:
         # stem
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
-        self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st)
         D, H, W = pl.in_dims
         sd, sh, sw = specs[0]["stride"]
-        self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]),
-                ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
+        if pre_np is not None and specs[0]["cout"] == 32:
+            # reduce came with the depthwise bwd-data above; the apply is fused into the stem weight gradient
+            self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, 32, S0, pl, st, pre_np=pre_np,
+                         apply=False)
+            self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(pl.bn_y[0]),
+                    ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W,
+                    sd, sh, sw, st)
+        else:
+            self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st,
+                         pre_np=pre_np)
+            self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input),
+                    ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         for fn in pending:
             fn()
         if ms:  # every gradient is complete once the side streams have been joined

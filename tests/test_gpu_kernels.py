@@ -154,6 +154,45 @@ def test_dw_bwd(N, C, dims, stride):
     close(dw.view(C, 1, 3, 3, 3), w.grad, 1e-4, 1e-4, "dw bwd weight")
 
 
+def test_fused_bn_backward_of_the_stem_tail():
+    """dw bwd-data emitting the BatchNorm-backward partials + stem bwd-weight applying the BatchNorm backward on load
+    == the unfused chain (bwd-data, reduce, finalize, apply, bwd-weight) on CPU autograd."""
+    L = _lib.load()
+    N, cin, dims = 2, 1, (12, 16, 24)
+    x = rnd(N, cin, *dims, seed=1)
+    w0 = rnd(32, cin, 3, 3, 3, seed=2, scale=0.3).requires_grad_(True)
+    gamma = (rnd(32, seed=3).abs() + 0.5).requires_grad_(True)
+    beta = rnd(32, seed=4, scale=0.2).requires_grad_(True)
+    w1 = rnd(32, 1, 3, 3, 3, seed=5, scale=0.4)
+    y0 = F.conv3d(x, w0, stride=2, padding=1)
+    a0 = torch.relu(F.batch_norm(y0, None, None, gamma, beta, True, 0.1, 1e-5))
+    z1 = F.conv3d(a0, w1, stride=2, padding=1, groups=32)
+    dz = rnd(*z1.shape, seed=6)
+    z1.backward(dz)
+    od, oh, ow = y0.shape[2:]
+    S0 = od * oh * ow
+    # forward statistics of y0 -> vec rows 0..3
+    yd = y0.detach().double()
+    part = torch.stack([yd.sum((0, 2, 3, 4)), (yd ** 2).sum((0, 2, 3, 4))]).view(2, 32, 1).contiguous().to(DEV)
+    vec = torch.zeros((6, 32), device=DEV)
+    _lib.call("msl_bn_finalize", ptr(part), 1, float(N * S0), ptr(K(gamma)), ptr(K(beta)), None, None, None, 0.1, 1e-5,
+              ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, st())
+    g = torch.full(y0.shape, float("nan"), device=DEV)
+    NP = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, 32, od, oh, ow)
+    bp = torch.zeros(2 * 32 * NP, dtype=torch.float64, device=DEV)
+    y0d = K(y0)
+    _lib.call("msl_dwconv_bwd_data_bnreduce", ptr(K(dz)), ptr(K(w1)), ptr(g), ptr(y0d), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+              ptr(vec[3]), ptr(bp), N, 32, od, oh, ow, 2, 0, st())
+    dgam, dbet = torch.empty(32, device=DEV), torch.empty(32, device=DEV)
+    _lib.call("msl_bn_bwd_finalize", ptr(bp), NP, float(N * S0), ptr(dgam), ptr(dbet), ptr(vec[4]), ptr(vec[5]), 32, st())
+    close(dgam, gamma.grad, 1e-4, 1e-5, "dgamma from fused reduce")
+    close(dbet, beta.grad, 1e-4, 1e-5, "dbeta from fused reduce")
+    dw = torch.empty((32, cin, 3, 3, 3), device=DEV)
+    ws = torch.empty(L.msl_stem_conv_bwd_weight_workspace_bytes(cin) // 4, device=DEV)
+    _lib.call("msl_stem_conv_bwd_weight_bnapply", ptr(g), ptr(y0d), ptr(vec), ptr(K(x)), ptr(dw), ptr(ws), N, cin, *dims, 2, 2, 2, st())
+    close(dw, w0.grad, 2e-4, 1e-4, "stem dW with fused BN apply")
+
+
 # ------------------------------------------------------------------------------------------------- pointwise
 @pytest.mark.parametrize("N,Cin,Cout,S", [(2, 32, 64, 1000), (1, 64, 128, 64), (2, 128, 128, 130), (1, 512, 512, 8),
                                           (1, 256, 512, 27)])
