@@ -156,10 +156,11 @@ int msl_multibox_loss_bwd(const float* locs, const float* scores, const long lon
                           const float* true_locs, const float* loss_out, const float* upstream, float* dlocs,
                           float* dscores, int N, int P, int ncls, void* stream);
 
-/* loss forward + backward for the training loop (2 launches; publishes loss_out as above) */
+/* loss forward + backward for the training loop (2 launches; publishes loss_out as above).  nan_flag (may be NULL):
+ * |= 1 if locs holds a NaN, |= 2 if scores does (the guards of ssd3d.py:258-261 without a pass of their own) */
 int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long long* true_classes,
                               const float* true_locs, double* workspace, float* loss_out, const float* upstream,
-                              float* dlocs, float* dscores, int N, int P, int ncls, void* stream);
+                              float* dlocs, float* dscores, int* nan_flag, int N, int P, int ncls, void* stream);
 
 /* ---- LSSD3D.detect_objects (ssd3d.py:344-460): softmax, decode, filter, sort, 3D NMS, top-k ---------------
  * cap = 10*top_k (<= 4096), Wn = ceil(cap/64), K1 = ncls-1.  Caller-allocated scratch:

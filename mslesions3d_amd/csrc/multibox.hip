@@ -247,10 +247,17 @@ __global__ __launch_bounds__(256) void multibox_loss_partial_kernel(const float*
                                                                     const float* __restrict__ scores,
                                                                     const long long* __restrict__ true_classes,
                                                                     const float* __restrict__ true_locs,
-                                                                    double* __restrict__ partials, int total, int ncls) {
+                                                                    double* __restrict__ partials, int total, int ncls,
+                                                                    int* __restrict__ nan_flag) {
   __shared__ double scratch[8];
   double ce = 0.0, l1 = 0.0, np = 0.0;
+  bool bad_loc = false, bad_score = false;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    if (nan_flag) {  // the NaN guards of ssd3d.py:258-261 for free: this kernel reads every loc and score anyway
+      for (int c = 0; c < ncls; ++c) bad_score |= isnan(scores[(size_t)i * ncls + c]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) bad_loc |= isnan(locs[(size_t)i * 6 + q]);
+    }
     const long long tc = true_classes[i];
     if (tc >= 0) {
       const float* x = scores + (size_t)i * ncls;
@@ -267,6 +274,10 @@ __global__ __launch_bounds__(256) void multibox_loss_partial_kernel(const float*
       for (int q = 0; q < 6; ++q) a += fabsf(locs[(size_t)i * 6 + q] - true_locs[(size_t)i * 6 + q]);
       l1 += (double)a;
     }
+  }
+  if (nan_flag) {
+    if (__any(bad_loc) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    if (__any(bad_score) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 2);
   }
   const double t0 = msl::block_sum(ce, scratch);
   __syncthreads();
@@ -432,7 +443,7 @@ int msl_multibox_loss_fwd(const float* locs, const float* scores, const long lon
   if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
-                     true_locs, workspace, N * P, ncls);
+                     true_locs, workspace, N * P, ncls, (int*)nullptr);
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(multibox_loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, LOSS_BLOCKS, loss_out);
   MSL_LAUNCH_CHECK();
@@ -455,11 +466,11 @@ int msl_multibox_loss_bwd(const float* locs, const float* scores, const long lon
 // partials itself and publishes loss_out = [conf, loc, n_positives]
 int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long long* true_classes,
                               const float* true_locs, double* workspace, float* loss_out, const float* upstream,
-                              float* dlocs, float* dscores, int N, int P, int ncls, void* stream) {
+                              float* dlocs, float* dscores, int* nan_flag, int N, int P, int ncls, void* stream) {
   if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
-                     true_locs, workspace, N * P, ncls);
+                     true_locs, workspace, N * P, ncls, nan_flag);
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(multibox_loss_bwd_kernel<true>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores,
                      true_classes, true_locs, loss_out, workspace, LOSS_BLOCKS, upstream, dlocs, dscores, N * P, ncls);

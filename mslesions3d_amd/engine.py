@@ -314,7 +314,7 @@ class Engine:
                       bn.eps, ptr(vec[0]), ptr(vec[1]), C, st)
 
     # ------------------------------------------------------------------------------------------------
-    def forward(self, x, training, need_grad, want_features=False):
+    def forward(self, x, training, need_grad, want_features=False, nan_check=True):
         """x (N,Cin,D,H,W) fp32 on the GPU -> (locs (N,P,6), scores (N,P,n_classes)) [+ dict of feature maps]."""
         if not x.is_cuda:
             raise _lib.HipKernelError("mslesions3d_amd runs on the HIP device only (no CPU fallback): move the "
@@ -411,8 +411,9 @@ class Engine:
             self._finalize_all(pl, bn_layers, st)
         if self.multi_stream:
             self._fork(pl, "fwd_heads_done", stH, st)
-        _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
-        _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
+        if nan_check:  # the fused training step lets the loss kernel set the flag instead (it reads both tensors anyway)
+            _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
+            _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
         if want_features:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores

@@ -617,20 +617,28 @@ class MultiBoxLoss(nn.Module):
             return float(self.threshold), 0.0, 0
         return float(self.threshold[0]), float(self.threshold[1]), 1
 
-    def _run_forward(self, st, locs, scores, gt_boxes, gt_labels, obj_off, T, with_backward_upstream=None):
-        """Matching + loss.  With ``with_backward_upstream`` (a 2-float device tensor [dL/dconf, dL/dloc]) the loss
-        gradient w.r.t. locs / scores is produced in the same call (training hot loop)."""
-        N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
-        assert P == self.priors_cxcycz.size(0) == scores.size(1)  # ssd3d.py:845
+    def _run_match(self, st, N, gt_boxes, gt_labels, obj_off, T, stream=None):
+        """Matching + target encoding only (depends on the ground truth and the priors, not on the network)."""
+        P = self.priors_cxcycz.size(0)
         lo, hi, soft = self._thresholds()
-        sm = _stream()
         _lib.call("msl_multibox_match", ptr(gt_boxes), ptr(gt_labels), ptr(obj_off), T, ptr(self.priors_cxcycz), N, P, lo,
                   hi, soft, ptr(st["overlap"]), ptr(st["obj"]), ptr(st["prior_for_obj"]), ptr(st["true_classes"]),
-                  ptr(st["true_locs"]), ptr(st["matched"]), sm)
+                  ptr(st["true_locs"]), ptr(st["matched"]), _stream() if stream is None else stream)
+
+    def _run_forward(self, st, locs, scores, gt_boxes, gt_labels, obj_off, T, with_backward_upstream=None,
+                     matched=False, nan_flag=None):
+        """Matching + loss.  With ``with_backward_upstream`` (a 2-float device tensor [dL/dconf, dL/dloc]) the loss
+        gradient w.r.t. locs / scores is produced in the same call (training hot loop); ``matched``: the targets
+        are already in ``st`` (the trainer runs the matching beside the forward pass)."""
+        N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
+        assert P == self.priors_cxcycz.size(0) == scores.size(1)  # ssd3d.py:845
+        sm = _stream()
+        if not matched:
+            self._run_match(st, N, gt_boxes, gt_labels, obj_off, T)
         if with_backward_upstream is not None:
             _lib.call("msl_multibox_loss_fwd_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
                       ptr(st["ws"]), ptr(st["loss_out"]), ptr(with_backward_upstream), ptr(st["dlocs"]), ptr(st["dscores"]),
-                      N, P, ncls, sm)
+                      ptr(nan_flag), N, P, ncls, sm)
             return
         _lib.call("msl_multibox_loss_fwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
                   ptr(st["ws"]), ptr(st["loss_out"]), N, P, ncls, sm)

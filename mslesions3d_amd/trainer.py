@@ -39,15 +39,24 @@ class FusedTrainer:
         """Issue every launch of one step through the Python executor (and record it if a recorder is active)."""
         m, eng, lf = self.model, self.model._engine, self.model.loss_fn
         dev = images.device
-        locs, scores = eng.forward(images, training=True, need_grad=True)
-        pl = eng.plan_for(images, True)
-        N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
+        N, P, ncls = images.shape[0], m.priors_cxcycz.shape[0], m.n_classes
         st = lf._state(N, P, ncls, total_objects, dev)
+        main = torch.cuda.current_stream().cuda_stream
+        if eng.multi_stream:
+            # the matching only needs the ground truth: run it on the heads stream beside the forward pass
+            pl0 = eng.plan_for(images, True)
+            sH = eng.side_streams(dev)[0].cuda_stream
+            eng._fork(pl0, "match_start", main, sH)
+            lf._run_match(st, N, gt_boxes, gt_labels, obj_off, total_objects, stream=sH)
+        locs, scores = eng.forward(images, training=True, need_grad=True, nan_check=False)
+        pl = eng.plan_for(images, True)
+        if eng.multi_stream:
+            eng._fork(pl, "match_done", sH, main)
         if "upstream_alpha" not in st or st["upstream_alpha_value"] != float(lf.alpha):
             st["upstream_alpha"] = torch.tensor([1.0, float(lf.alpha)], dtype=torch.float32, device=dev)  # loss = conf + alpha*loc
             st["upstream_alpha_value"] = float(lf.alpha)
         lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects,
-                        with_backward_upstream=st["upstream_alpha"])
+                        with_backward_upstream=st["upstream_alpha"], matched=eng.multi_stream, nan_flag=pl.nan_flag)
         eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red)
         scale = red.finish()
         if red.world > 1:
