@@ -139,13 +139,22 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_reduce_kernel(
   const int lo = chunk * BWD_CHUNK, hi = min(S, lo + BWD_CHUNK);
   float s1 = 0.f, s2 = 0.f;
   if ((S & 3) == 0) {
-    for (int i = lo + threadIdx.x * 4; i < hi; i += 256 * 4) {
-      const float4 gv = *reinterpret_cast<const float4*>(g + base + i);
-      const float4 yv = *reinterpret_cast<const float4*>(y + base + i);
-      const float ga[4] = {gv.x, gv.y, gv.z, gv.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+    // BWD_CHUNK = 4 x 1024: the thread's four float4 pairs are loaded back to back (clamped addresses, masked)
+    float4 gv[4], yv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = lo + threadIdx.x * 4 + u * 1024;
+      const size_t o = base + (i < hi ? i : lo);
+      gv[u] = *reinterpret_cast<const float4*>(g + o);
+      yv[u] = *reinterpret_cast<const float4*>(y + o);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const bool in = lo + threadIdx.x * 4 + u * 1024 < hi;
+      const float ga[4] = {gv[u].x, gv[u].y, gv[u].z, gv[u].w}, ya[4] = {yv[u].x, yv[u].y, yv[u].z, yv[u].w};
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
-        const float gm = fmaf(ya[k], sc, sh) > 0.f ? ga[k] : 0.f;
+        const float gm = (in && fmaf(ya[k], sc, sh) > 0.f) ? ga[k] : 0.f;
         s1 += gm;
         s2 += gm * ((ya[k] - mu) * is);
       }
@@ -291,6 +300,67 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_fused_kernel(
   }
 }
 
+// Register-resident form of the above for N*S <= NT*IPT*4 elements per channel (S % 4 == 0): the channel's g and y are
+// read ONCE, all loads of a thread in flight together, kept in registers across the reduction, and dL/dy is written from
+// them - one memory round trip, a block-wide reduction, one burst of stores.
+template <int NT, int IPT>
+__global__ __launch_bounds__(NT) void bn_relu_bwd_fused_reg_kernel(
+    const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, float* __restrict__ dy, int N, int C, int S, double count) {
+  __shared__ double scratch[16];
+  __shared__ float coef[2];
+  const int c = blockIdx.x;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+  const int S4 = S >> 2, total4 = N * S4;
+  float4 gv[IPT], yv[IPT];
+  size_t off[IPT];
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    const int t = threadIdx.x + u * NT;
+    const int tt = t < total4 ? t : 0;
+    const int n = tt / S4, i4 = tt - n * S4;
+    off[u] = ((size_t)n * C + c) * S + (size_t)i4 * 4;
+    gv[u] = *reinterpret_cast<const float4*>(g + off[u]);
+    yv[u] = *reinterpret_cast<const float4*>(y + off[u]);
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    const bool in = threadIdx.x + u * NT < total4;
+    float* ga = reinterpret_cast<float*>(&gv[u]);
+    const float* ya = reinterpret_cast<const float*>(&yv[u]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      ga[k] = (in && fmaf(ya[k], sc, sh) > 0.f) ? ga[k] : 0.f;  // gm
+      s1 += ga[k];
+      s2 += ga[k] * ((ya[k] - mu) * is);
+    }
+  }
+  const double t1 = msl::block_sum((double)s1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+    coef[0] = (float)(t1 / count);
+    coef[1] = (float)(t2 / count);
+  }
+  __syncthreads();
+  const float k1 = coef[0], k2 = coef[1];
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    if (threadIdx.x + u * NT < total4) {
+      const float* ga = reinterpret_cast<const float*>(&gv[u]);
+      const float* ya = reinterpret_cast<const float*>(&yv[u]);
+      float o[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = sc * (ga[k] - k1 - ((ya[k] - mu) * is) * k2);
+      *reinterpret_cast<float4*>(dy + off[u]) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -400,7 +470,23 @@ int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, co
                           const float* invstd, float* dgamma, float* dbeta, float* dy, int N, int C, int S,
                           void* stream) {
   if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_relu_bwd_fused_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, g, y, scale, shift, mean,
+  hipStream_t st = (hipStream_t)stream;
+  const long long total4 = (long long)N * (S >> 2);
+#define MSL_BN_REG(NT_, IPT_)                                                                                          \
+  hipLaunchKernelGGL((bn_relu_bwd_fused_reg_kernel<NT_, IPT_>), dim3(C), dim3(NT_), 0, st, g, y, scale, shift, mean, \
+                     invstd, dgamma, dbeta, dy, N, C, S, (double)N * S)
+  if ((S & 3) == 0 && total4 <= 4096) {
+    if (total4 <= 64) MSL_BN_REG(64, 1);
+    else if (total4 <= 256) MSL_BN_REG(256, 1);
+    else if (total4 <= 512) MSL_BN_REG(256, 2);
+    else if (total4 <= 1024) MSL_BN_REG(512, 2);
+    else if (total4 <= 2048) MSL_BN_REG(1024, 2);
+    else MSL_BN_REG(1024, 4);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
+#undef MSL_BN_REG
+  hipLaunchKernelGGL(bn_relu_bwd_fused_kernel, dim3(C), dim3(256), 0, st, g, y, scale, shift, mean,
                      invstd, dgamma, dbeta, dy, N, C, S, (double)N * S);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

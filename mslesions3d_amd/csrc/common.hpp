@@ -30,6 +30,30 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// row[col .. col+3] of a row of S floats, zero past the end.  The loads are unconditional on clamped (always valid)
+// addresses and masked afterwards: a predicated load compiles to a branch per load, and the compiler then waits for
+// each one before it issues the next - the loads of a tile must leave back to back.
+// VEC: S % 4 == 0, col % 4 == 0 and the row 16-byte aligned (then col < S implies col + 3 < S).
+template <bool VEC>
+__device__ __forceinline__ float4 load4_zfill(const float* __restrict__ row, int col, int S) {
+  float4 v;
+  if (VEC) {
+    const bool in = col < S;
+    v = *reinterpret_cast<const float4*>(row + (in ? col : 0));
+    v.x = in ? v.x : 0.f; v.y = in ? v.y : 0.f; v.z = in ? v.z : 0.f; v.w = in ? v.w : 0.f;
+  } else {
+    const int last = S - 1;
+    v.x = row[min(col, last)]; v.y = row[min(col + 1, last)]; v.z = row[min(col + 2, last)]; v.w = row[min(col + 3, last)];
+    v.x = col < S ? v.x : 0.f; v.y = col + 1 < S ? v.y : 0.f; v.z = col + 2 < S ? v.z : 0.f; v.w = col + 3 < S ? v.w : 0.f;
+  }
+  return v;
+}
+
+// Force a loaded value into its register HERE.  Without it the optimiser sinks a load into the conditional block
+// that is its only user, which turns "issue U loads, then use them" back into U serial round trips.
+__device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void pin(float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); }
+
 // Sum over the whole block (blockDim.x multiple of 64, <= 1024).  Result valid in thread 0.
 // `scratch` must hold >= blockDim.x/64 doubles; the caller must __syncthreads() before reusing it.
 __device__ __forceinline__ double block_sum(double v, double* scratch) {

@@ -397,6 +397,7 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
     msl::BnFold fold) {
   extern __shared__ __align__(16) float lds[];
   __shared__ float s_sc[64], s_sh[64];
+  __shared__ float s_w[MODE == 0 ? 64 * 27 : 1];  // the G channels' taps (G <= 64): fetched with the prologue, not per item
   const int wbase = flip ? 26 : 0, wsgn = flip ? -1 : 1;  // flipped taps: stride-1 bwd-data == forward with w[26-k]
   const int lb = xcd_remap(blockIdx.x, gridDim.x);
   const int slab = lb % nslabs;
@@ -418,6 +419,9 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
   const int nitems = G * L;
   const int W4 = W >> 2, plane4 = H * W4;
 
+  if (MODE == 0) {
+    for (int i = threadIdx.x; i < G * 27; i += 256) s_w[i] = w[(size_t)c0 * 27 + i];
+  }
   for (int i = threadIdx.x; i < G * CS; i += 256) lds[i] = 0.f;
   const bool affine = in_scale != nullptr || fold.partials != nullptr;
   if (fold.partials) {
@@ -430,20 +434,40 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
     __syncthreads();
   }
   const int tot4 = G * NPL * plane4;
-  for (int q = threadIdx.x; q < tot4; q += 256) {
-    const int g = q / (NPL * plane4);
-    const int r1 = q % (NPL * plane4);
-    const int pl = r1 / plane4, rem = r1 % plane4;
-    const int p = p0 + pl;
-    if (p < 0 || p >= D) continue;
-    const int ih = rem / W4, iw = (rem % W4) * 4;
-    float4 v = *reinterpret_cast<const float4*>(x + (((size_t)n * C + c0 + g) * D + p) * H * W + (size_t)rem * 4);
-    if (affine) {
-      const float sc = s_sc[g], sh = s_sh[g];
-      v.x = msl::act(v.x, sc, sh); v.y = msl::act(v.y, sc, sh);
-      v.z = msl::act(v.z, sc, sh); v.w = msl::act(v.w, sc, sh);
+  // 4 independent 16-byte loads in flight per thread (unconditional, on clamped addresses; see msl::pin)
+  for (int q0 = threadIdx.x; q0 < tot4; q0 += 4 * 256) {
+    float4 v[4];
+    int dst[4];  // LDS row offset, -1 = nothing to store
+    int iwv[4], gv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int q = q0 + u * 256;
+      const bool live = q < tot4;
+      const int qq = live ? q : 0;
+      const int g = qq / (NPL * plane4);
+      const int r1 = qq % (NPL * plane4);
+      const int pl = r1 / plane4, rem = r1 % plane4;
+      const int p = p0 + pl;
+      const bool ok = live && p >= 0 && p < D;
+      const int ih = rem / W4;
+      iwv[u] = (rem % W4) * 4;
+      gv[u] = g;
+      dst[u] = ok ? g * CS + pl * PS + (ih + 1) * RS : -1;
+      v[u] = *reinterpret_cast<const float4*>(x + (((size_t)n * C + c0 + g) * D + (ok ? p : 0)) * H * W + (size_t)rem * 4);
     }
-    store_row4<STRIDE>(lds + g * CS + pl * PS + (ih + 1) * RS, iw, EW, v.x, v.y, v.z, v.w);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) msl::pin(v[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (dst[u] < 0) continue;
+      float4 t = v[u];
+      if (affine) {
+        const float sc = s_sc[gv[u]], sh = s_sh[gv[u]];
+        t.x = msl::act(t.x, sc, sh); t.y = msl::act(t.y, sc, sh);
+        t.z = msl::act(t.z, sc, sh); t.w = msl::act(t.w, sc, sh);
+      }
+      store_row4<STRIDE>(lds + dst[u], iwv[u], EW, t.x, t.y, t.z, t.w);
+    }
   }
   __syncthreads();
 
@@ -482,7 +506,7 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
     const int g = item / L, r0 = item % L;
     const int odl = r0 / Lp, r1 = r0 % Lp;
     const int oh = r1 / OWV, ow = (r1 % OWV) * 4;
-    const float* wc = w + (size_t)(c0 + g) * 27;
+    const float* wc = s_w + g * 27;
     float acc[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
@@ -649,7 +673,7 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
     SLAB /= 2;
   int NPL = stride * SLAB + (stride == 2 ? 1 : 2);
   size_t per_ch = (size_t)NPL * PS * 4 + (size_t)2 * SLAB * Lp * 4;
-  if (per_ch > 160 * 1024) {
+  if (per_ch > 150 * 1024) {  // + 7.5 KB of static LDS
     pl.variant = 0;
     pl.num_partials = N * msl::cdiv(S, STATS_CHUNK);
     return pl;

@@ -148,6 +148,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
 #pragma unroll
   for (int k = 0; k < 27; ++k) wk[k] = w[c * 27 + k];
   const float* dyc = dy + (size_t)nc * OD * OH * OW;
+  // every global read of the thread is issued here, unconditionally on clamped addresses (masked afterwards), so
+  // they share one memory round trip: the 12 gradients, and the 4 destination rows' previous gradient (accumulate)
+  // and forward value (REDUCE)
   float dv[2][2][3];
 #pragma unroll
   for (int dd = 0; dd < 2; ++dd)
@@ -156,8 +159,39 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
 #pragma unroll
       for (int ww = 0; ww < 3; ++ww) {
         const bool ok = a + dd < OD && b + hh < OH && c2 + ww < OW;
-        dv[dd][hh][ww] = ok ? dyc[((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww] : 0.f;
+        const float v = dyc[ok ? ((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww : 0];
+        dv[dd][hh][ww] = ok ? v : 0.f;
       }
+  bool okp[2][2];
+  size_t offp[2][2];
+  float4 yv[2][2], old[2][2];
+#pragma unroll
+  for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      const int id = 2 * a + pd, ih = 2 * b + ph;
+      okp[pd][ph] = live && id < D && ih < H;
+      offp[pd][ph] = (size_t)nc * D * H * W + (okp[pd][ph] ? ((size_t)id * H + ih) * W + iw0 : 0);
+      if (REDUCE) yv[pd][ph] = *reinterpret_cast<const float4*>(y_prev + offp[pd][ph]);
+    }
+  if (accumulate) {
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) old[pd][ph] = *reinterpret_cast<const float4*>(g_in + offp[pd][ph]);
+  } else {
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) old[pd][ph] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+#pragma unroll
+  for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+      if (REDUCE) msl::pin(yv[pd][ph]);
+      msl::pin(old[pd][ph]);
+    }
   // per axis: even index -> (offset 0, k = 1); odd index -> (offset 1, k = 0) and (offset 0, k = 2)
   float g[2][2][4];
 #pragma unroll
@@ -191,19 +225,13 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
   for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-      const int id = 2 * a + pd, ih = 2 * b + ph;
-      if (live && id < D && ih < H) {
-        const size_t off = (size_t)nc * D * H * W + ((size_t)id * H + ih) * W + iw0;
-        float* dst = g_in + off;
-        float4 v = make_float4(g[pd][ph][0], g[pd][ph][1], g[pd][ph][2], g[pd][ph][3]);
-        if (accumulate) {
-          const float4 old = *reinterpret_cast<const float4*>(dst);
-          v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-        }
-        *reinterpret_cast<float4*>(dst) = v;
+      if (okp[pd][ph]) {
+        const float4 o = old[pd][ph];
+        const float4 v = make_float4(g[pd][ph][0] + o.x, g[pd][ph][1] + o.y, g[pd][ph][2] + o.z, g[pd][ph][3] + o.w);
+        *reinterpret_cast<float4*>(g_in + offp[pd][ph]) = v;
         if (REDUCE) {
-          const float4 yv = *reinterpret_cast<const float4*>(y_prev + off);
-          const float ga[4] = {v.x, v.y, v.z, v.w}, ya[4] = {yv.x, yv.y, yv.z, yv.w};
+          const float4 y4 = yv[pd][ph];
+          const float ga[4] = {v.x, v.y, v.z, v.w}, ya[4] = {y4.x, y4.y, y4.z, y4.w};
 #pragma unroll
           for (int k = 0; k < 4; ++k) {
             const float gm = fmaf(ya[k], sc, sh) > 0.f ? ga[k] : 0.f;

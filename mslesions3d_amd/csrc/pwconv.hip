@@ -31,40 +31,43 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
   __shared__ float Ws[BM][WS_LD];
   __shared__ float red[2][2][BM];  // [sum|sumsq][wave column][row]
   __shared__ float f_sc[AFFINE ? FOLD_MAXK : 1], f_sh[AFFINE ? FOLD_MAXK : 1];
-  if (AFFINE) {
-    if (fold.partials) {
-      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
-    } else {
-      for (int k = threadIdx.x; k < K && k < FOLD_MAXK; k += blockDim.x) {
-        f_sc[k] = in_scale[k];
-        f_sh[k] = in_shift[k];
-      }
-      __syncthreads();
-    }
-  }
   const int n = blockIdx.z, m0 = blockIdx.y * BM, s0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv >> 1, wn = wv & 1;  // 2 x 2 waves: 32 rows x 64 columns each
   const float* Xn = X + (size_t)n * K * S;
   const bool vec_ok = (S & 3) == 0;
 
-  f32x16 acc0 = {0}, acc1 = {0};
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    // ---- stage activations: 32 rows x 128 columns
+  // chunk k0: 32 activation rows x 128 columns + 64 x 32 weights, through registers (the next chunk's loads are in
+  // flight during this chunk's MFMAs)
+  float4 xr[4], wr[2];
+  auto load_chunk = [&](int k0) {
+    if (vec_ok) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xr[i] = msl::load4_zfill<true>(Xn + (size_t)(k0 + (tid >> 5) + i * 8) * S, s0 + (tid & 31) * 4, S);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xr[i] = msl::load4_zfill<false>(Xn + (size_t)(k0 + (tid >> 5) + i * 8) * S, s0 + (tid & 31) * 4, S);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      if (!TRANS_W) {
+        const int m = (tid >> 3) + i * 32, k4 = (tid & 7) * 4;
+        // rows >= M read row 0: their products land in output rows that are never stored or counted
+        wr[i] = *reinterpret_cast<const float4*>(Wt + (size_t)(m0 + m < M ? m0 + m : 0) * K + k0 + k4);
+      } else {
+        const int k = (tid >> 4) + i * 16, m4 = (tid & 15) * 4;
+        // M % 4 == 0; columns >= M read column 0 (output rows that are never stored)
+        wr[i] = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + k) * M + (m0 + m4 < M ? m0 + m4 : 0));
+      }
+    }
+  };
+  auto store_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int r = (tid >> 5) + i * 8, c4 = (tid & 31) * 4;
-      const int col = s0 + c4;
-      const float* src = Xn + (size_t)(k0 + r) * S + col;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vec_ok && col + 3 < S) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
-        if (col < S) v.x = src[0];
-        if (col + 1 < S) v.y = src[1];
-        if (col + 2 < S) v.z = src[2];
-        if (col + 3 < S) v.w = src[3];
-      }
+      const int r = (tid >> 5) + i * 8, c4 = (tid & 31) * 4, col = s0 + c4;
+      float4 v = xr[i];
       if (AFFINE) {
         const float sc = f_sc[k0 + r], sh = f_sh[k0 + r];
         v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
@@ -74,25 +77,38 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
       }
       *reinterpret_cast<float4*>(&Xs[r][c4]) = v;
     }
-    // ---- stage weights: 64 x 32
-    if (!TRANS_W) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 2; ++i) {
+      const float4 v = wr[i];
+      if (!TRANS_W) {
         const int m = (tid >> 3) + i * 32, k4 = (tid & 7) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + m < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(m0 + m) * K + k0 + k4);
         Ws[m][k4] = v.x; Ws[m][k4 + 1] = v.y; Ws[m][k4 + 2] = v.z; Ws[m][k4 + 3] = v.w;
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
+      } else {
         const int k = (tid >> 4) + i * 16, m4 = (tid & 15) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (m0 + m4 + 3 < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + k) * M + m0 + m4);
         Ws[m4][k] = v.x; Ws[m4 + 1][k] = v.y; Ws[m4 + 2][k] = v.z; Ws[m4 + 3][k] = v.w;
       }
     }
+  };
+
+  f32x16 acc0 = {0}, acc1 = {0};
+  load_chunk(0);
+  // the input affine goes to LDS behind the first chunk's loads (one memory round trip for both); the chunk loop's
+  // first barrier publishes it
+  if (AFFINE) {
+    if (fold.partials) {
+      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
+    } else {
+      for (int k = threadIdx.x; k < K && k < FOLD_MAXK; k += blockDim.x) {
+        f_sc[k] = in_scale[k];
+        f_sh[k] = in_shift[k];
+      }
+    }
+  }
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    __syncthreads();  // the previous chunk has been consumed
+    store_chunk(k0);
     __syncthreads();
+    if (k0 + BK < K) load_chunk(k0 + BK);
 #pragma unroll
     for (int kk = 0; kk < BK / 2; ++kk) {
       const int kr = 2 * kk + (lane >> 5);
@@ -102,7 +118,6 @@ __global__ __launch_bounds__(256) void pw_gemm_kernel(const float* __restrict__ 
       acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b0, acc0, 0, 0, 0);
       acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b1, acc1, 0, 0, 0);
     }
-    __syncthreads();
   }
 
   // ---- epilogue: D[row][col]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
@@ -156,17 +171,6 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
                                                              msl::BnFold fold) {
   extern __shared__ __align__(16) float lds[];  // NW * KS_WAVE_LDS floats
   __shared__ float f_sc[AFFINE ? FOLD_MAXK : 1], f_sh[AFFINE ? FOLD_MAXK : 1];
-  if (AFFINE) {
-    if (fold.partials) {
-      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
-    } else {
-      for (int k = threadIdx.x; k < K && k < FOLD_MAXK; k += blockDim.x) {
-        f_sc[k] = in_scale[k];
-        f_sh[k] = in_shift[k];
-      }
-      __syncthreads();
-    }
-  }
   const int n = blockIdx.z, m0 = blockIdx.y * KS_BM, s0 = blockIdx.x * KS_BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   float* Xs = lds + wv * KS_WAVE_LDS;   // [BK][KS_BN]
@@ -179,19 +183,33 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
 
   float4 xr[8], wr[4];
   auto load_chunk = [&](int k0) {
+    if (vec_ok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        xr[i] = msl::load4_zfill<true>(Xn + (size_t)(k0 + (lane >> 4) + i * 4) * S, s0 + (lane & 15) * 4, S);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+        xr[i] = msl::load4_zfill<false>(Xn + (size_t)(k0 + (lane >> 4) + i * 4) * S, s0 + (lane & 15) * 4, S);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (!TRANS_W) {
+        const int m = (lane >> 3) + i * 8, k4 = (lane & 7) * 4;
+        // rows >= M read row 0: their products land in output rows that are never stored or counted
+        wr[i] = *reinterpret_cast<const float4*>(Wt + (size_t)(m0 + m < M ? m0 + m : 0) * K + k0 + k4);
+      } else {
+        const int k = (lane >> 3) + i * 8, m4 = (lane & 7) * 4;
+        // M % 4 == 0; columns >= M read column 0 (output rows that are never stored)
+        wr[i] = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + k) * M + (m0 + m4 < M ? m0 + m4 : 0));
+      }
+    }
+  };
+  auto store_chunk = [&](int k0) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int r = (lane >> 4) + i * 4, c4 = (lane & 15) * 4, col = s0 + c4;
-      const float* src = Xn + (size_t)(k0 + r) * S + col;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vec_ok && col + 3 < S) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
-        if (col < S) v.x = src[0];
-        if (col + 1 < S) v.y = src[1];
-        if (col + 2 < S) v.z = src[2];
-        if (col + 3 < S) v.w = src[3];
-      }
+      float4 v = xr[i];
       if (AFFINE) {
         const float sc = f_sc[k0 + r], sh = f_sh[k0 + r];
         v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
@@ -199,26 +217,7 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
         v.z = col + 2 < S ? msl::act(v.z, sc, sh) : 0.f;
         v.w = col + 3 < S ? msl::act(v.w, sc, sh) : 0.f;
       }
-      xr[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!TRANS_W) {
-        const int m = (lane >> 3) + i * 8, k4 = (lane & 7) * 4;
-        if (m0 + m < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(m0 + m) * K + k0 + k4);
-      } else {
-        const int k = (lane >> 3) + i * 8, m4 = (lane & 7) * 4;
-        if (m0 + m4 + 3 < M) v = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + k) * M + m0 + m4);
-      }
-      wr[i] = v;
-    }
-  };
-  auto store_chunk = [&]() {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int r = (lane >> 4) + i * 4, c4 = (lane & 15) * 4;
-      *reinterpret_cast<float4*>(Xs + r * KS_BN + c4) = xr[i];
+      *reinterpret_cast<float4*>(Xs + r * KS_BN + c4) = v;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -236,9 +235,21 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
 
   f32x16 acc0 = {0}, acc1 = {0};
   load_chunk(kbeg);
+  // the input affine goes to LDS behind the first chunk's loads (one memory round trip for both); the chunk loop's
+  // first barrier publishes it
+  if (AFFINE) {
+    if (fold.partials) {
+      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
+    } else {
+      for (int k = threadIdx.x; k < K && k < FOLD_MAXK; k += blockDim.x) {
+        f_sc[k] = in_scale[k];
+        f_sh[k] = in_shift[k];
+      }
+    }
+  }
   for (int ch = 0; ch < nchunks; ++ch) {
     __syncthreads();  // the previous chunk has been consumed
-    store_chunk();
+    store_chunk(kbeg + ch * BK);
     __syncthreads();
     if (ch + 1 < nchunks) load_chunk(kbeg + (ch + 1) * BK);
 #pragma unroll
@@ -340,21 +351,25 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
     const int n = ch / chunks_per_img, s0 = (ch % chunks_per_img) * PC;
     const float* dyn = dY + ((size_t)n * Cout + m0) * S;
     const float* zn = Z + ((size_t)n * Cin + n0) * S;
+    float4 st[(64 + BNN) / 16];
+    if (vec_ok) {
+#pragma unroll
+      for (int i = 0; i < (64 + BNN) / 16; ++i) {
+        const int r = (tid >> 4) + i * 16;
+        st[i] = msl::load4_zfill<true>(r < 64 ? dyn + (size_t)r * S : zn + (size_t)(r - 64) * S, s0 + (tid & 15) * 4, S);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < (64 + BNN) / 16; ++i) {
+        const int r = (tid >> 4) + i * 16;
+        st[i] = msl::load4_zfill<false>(r < 64 ? dyn + (size_t)r * S : zn + (size_t)(r - 64) * S, s0 + (tid & 15) * 4, S);
+      }
+    }
 #pragma unroll
     for (int i = 0; i < (64 + BNN) / 16; ++i) {
       const int r = (tid >> 4) + i * 16, c4 = (tid & 15) * 4, col = s0 + c4;
-      const bool isdy = r < 64;
-      const float* src = isdy ? dyn + (size_t)r * S + col : zn + (size_t)(r - 64) * S + col;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (vec_ok && col + 3 < S) {
-        v = *reinterpret_cast<const float4*>(src);
-      } else {
-        if (col < S) v.x = src[0];
-        if (col + 1 < S) v.y = src[1];
-        if (col + 2 < S) v.z = src[2];
-        if (col + 3 < S) v.w = src[3];
-      }
-      if (AFFINE && !isdy) {
+      float4 v = st[i];
+      if (AFFINE && r >= 64) {  // uniform per i: 64 % 16 == 0
         const float sc = in_scale[n0 + r - 64], sh = in_shift[n0 + r - 64];
         v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
         v.y = col + 1 < S ? msl::act(v.y, sc, sh) : 0.f;

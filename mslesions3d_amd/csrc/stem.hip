@@ -158,24 +158,24 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     __syncthreads();  // previous chunk's LDS reads are done
     // Issue every global load of the chunk first (32 dy + 9*CIN*3 input values per lane in flight), then
     // store to LDS: a load->store->load chain would expose the full memory latency 59 times per chunk.
-    float dreg[32];
+    // Every load is unconditional on a clamped (always valid) address and masked afterwards: a predicated load
+    // becomes a branch per load, and the compiler then waits for each one before issuing the next.  The
+    // sched_barrier keeps the machine scheduler from re-interleaving the loads with their uses to save VGPRs.
+    float dreg[32], yreg[APPLY ? 32 : 1];
+    const bool in = lane < npos;
     {
-      const size_t off = (size_t)n * 32 * OS + ((size_t)od * OH + oh) * OW + ow0 + lane;
+      const size_t off = (size_t)n * 32 * OS + ((size_t)od * OH + oh) * OW + ow0 + (in ? lane : 0);
       const float* src = dy + off;
 #pragma unroll
-      for (int co = 0; co < 32; ++co) dreg[co] = lane < npos ? src[(size_t)co * OS] : 0.f;
+      for (int co = 0; co < 32; ++co) dreg[co] = src[(size_t)co * OS];
       if (APPLY) {
         const float* ysrc = yraw + off;
 #pragma unroll
-        for (int co = 0; co < 32; ++co) {
-          const float yv = lane < npos ? ysrc[(size_t)co * OS] : 0.f;
-          const float sc = bnv[co], sf = bnv[32 + co], mu = bnv[64 + co], is = bnv[96 + co];
-          const float gm = fmaf(yv, sc, sf) > 0.f ? dreg[co] : 0.f;
-          dreg[co] = lane < npos ? sc * (gm - bnv[128 + co] - ((yv - mu) * is) * bnv[160 + co]) : 0.f;
-        }
+        for (int co = 0; co < 32; ++co) yreg[co] = ysrc[(size_t)co * OS];
       }
     }
     float xreg[CIN * 9][3];
+    bool xok[CIN * 9][3];
     {
       const int iw0 = ow0 * sw - 1;
       const int span = 64 * sw + 1;  // j in [0, span]
@@ -189,10 +189,30 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
 #pragma unroll
           for (int t = 0; t < 3; ++t) {
             const int j = lane + 64 * t, iw = iw0 + j;
-            xreg[ci * 9 + rr][t] = (rok && j <= span && iw >= 0 && iw < W) ? src[iw] : 0.f;
+            xok[ci * 9 + rr][t] = rok && j <= span && iw >= 0 && iw < W;
+            xreg[ci * 9 + rr][t] = src[xok[ci * 9 + rr][t] ? iw : 0];
           }
         }
     }
+    __builtin_amdgcn_sched_barrier(0);  // everything above is in flight before anything below waits
+    if (APPLY) {
+#pragma unroll
+      for (int co = 0; co < 32; ++co) {
+        const float yv = yreg[co];
+        const float sc = bnv[co], sf = bnv[32 + co], mu = bnv[64 + co], is = bnv[96 + co];
+        const float gm = fmaf(yv, sc, sf) > 0.f ? dreg[co] : 0.f;
+        dreg[co] = sc * (gm - bnv[128 + co] - ((yv - mu) * is) * bnv[160 + co]);
+      }
+    }
+#pragma unroll
+    for (int co = 0; co < 32; ++co) dreg[co] = in ? dreg[co] : 0.f;
+#pragma unroll
+    for (int r2 = 0; r2 < CIN * 9; ++r2)
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        xreg[r2][t] = xok[r2][t] ? xreg[r2][t] : 0.f;
+        if (t == 2) asm volatile("" : "+v"(xreg[r2][t]));  // pin it here: else the load is sunk into the conditional store
+      }
 #pragma unroll
     for (int co = 0; co < 32; ++co) dyt[co * SB_DY_LD + lane] = dreg[co];
 #pragma unroll
