@@ -317,6 +317,192 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
 }
 
 // ---------------------------------------------------------------------------------------------
+// Wave-autonomous variant (the default for channel counts that are multiples of 32).  A wave owns a 32-row x
+// 32-column output tile over KW input channels and feeds the MFMA straight from registers:
+//   B operand  lane (h, c) holds X[kb + h*KW/2 + kk][col0 + c], kk = 0..KW/2-1  - one coalesced dword load per kk
+//   A operand  lane (h, c) holds W[m0 + c][kb + h*KW/2 + kk]                    - contiguous in k: 16-byte loads
+//              (bwd-data reads W^T: element (m, k) = W[k*M + m], one coalesced dword load per kk)
+// so MFMA step kk multiplies k = kb + kk (lanes 0-31) and k = kb + KW/2 + kk (lanes 32-63).  No LDS staging and no
+// barrier before the MFMAs: every load of the wave is in flight at once (one memory round trip), and waves drift
+// apart, so loads, MFMAs and stores of different waves overlap instead of marching in phases.
+//   NWK == 1 (K = KW = 32 | 64): a workgroup is 4 waves = 4 neighbouring column tiles, MT row tiles each.
+//   NWK  > 1 (K = NWK * 64):     a workgroup is one tile; wave j takes channels [64j, 64j+64); the NWK partial tiles
+//                                meet in LDS and every wave finishes 32/NWK rows (sum order j = 0..NWK-1, fixed).
+constexpr int WV_LD = 33;
+
+template <int KW, int MT, bool AFFINE, bool STATS, bool TRANS_W, int NWK>
+__global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
+    const float* __restrict__ X, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ Wt, float* __restrict__ Y, double* __restrict__ partials, int M, int K, int S,
+    msl::BnFold fold) {
+  constexpr int KH = KW / 2;
+  static_assert(NWK == 1 || MT == 1, "the K-split form owns one row tile");
+  __shared__ float red[NWK == 1 ? 2 * 4 * MT * 32 : NWK * 32 * WV_LD];
+  __shared__ float f_sc[AFFINE ? FOLD_MAXK : 1], f_sh[AFFINE ? FOLD_MAXK : 1];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+  const int n = blockIdx.z;
+  const int m0 = blockIdx.y * 32 * MT;
+  const int ctile = NWK == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+  const int kb = (NWK == 1 ? 0 : wv * KW) + h * KH;  // this lane's first input channel
+  const int col = ctile * 32 + c;
+  const bool cin = col < S;
+
+  float xr[KH], wr[MT][KH];
+  {
+    const float* xp = X + ((size_t)n * K + kb) * S + (cin ? col : S - 1);
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) xr[kk] = xp[(size_t)kk * S];
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    if (!TRANS_W) {
+      const float4* wp = reinterpret_cast<const float4*>(Wt + (size_t)(m0 + mt * 32 + c) * K + kb);
+#pragma unroll
+      for (int j = 0; j < KH / 4; ++j) {
+        const float4 t = wp[j];
+        wr[mt][4 * j] = t.x; wr[mt][4 * j + 1] = t.y; wr[mt][4 * j + 2] = t.z; wr[mt][4 * j + 3] = t.w;
+      }
+    } else {
+      const float* wp = Wt + (size_t)kb * M + m0 + mt * 32 + c;
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk) wr[mt][kk] = wp[(size_t)kk * M];
+    }
+  }
+  // all of the above leaves before anything below waits (the scheduler would otherwise trade the memory-level
+  // parallelism for registers: load two, wait, MFMA, ...)
+  __builtin_amdgcn_sched_barrier(0);
+  if (AFFINE) {
+    if (fold.partials) {  // optional in-kernel BatchNorm fold (Engine.fold_bn): same (scale, shift) bits as the vectors
+      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk) xr[kk] = cin ? msl::act(xr[kk], f_sc[kb + kk], f_sh[kb + kk]) : 0.f;
+    } else {
+      float sc[KH], sh[KH];
+      const float4* sp = reinterpret_cast<const float4*>(in_scale + kb);
+      const float4* hp = reinterpret_cast<const float4*>(in_shift + kb);
+#pragma unroll
+      for (int j = 0; j < KH / 4; ++j) {
+        const float4 a = sp[j], b = hp[j];
+        sc[4 * j] = a.x; sc[4 * j + 1] = a.y; sc[4 * j + 2] = a.z; sc[4 * j + 3] = a.w;
+        sh[4 * j] = b.x; sh[4 * j + 1] = b.y; sh[4 * j + 2] = b.z; sh[4 * j + 3] = b.w;
+      }
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk) xr[kk] = cin ? msl::act(xr[kk], sc[kk], sh[kk]) : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) xr[kk] = cin ? xr[kk] : 0.f;
+  }
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x16){0};
+#pragma unroll
+  for (int kk = 0; kk < KH; ++kk)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[mt][kk], xr[kk], acc[mt], 0, 0, 0);
+
+  float* Yn = Y + (size_t)n * M * S;
+  const int NP = gridDim.z * gridDim.x, p = n * gridDim.x + blockIdx.x;
+  if (NWK == 1) {
+    // D[row][col]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+        const float v = acc[mt][r];
+        if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
+        if (STATS) {
+          float sm = v, q = v * v;  // columns past S hold exact zeros
+#pragma unroll
+          for (int o = 16; o > 0; o >>= 1) {
+            sm += __shfl_xor(sm, o, 64);
+            q += __shfl_xor(q, o, 64);
+          }
+          if (c == 0) {
+            red[(wv * MT * 32 + row) * 2] = sm;
+            red[(wv * MT * 32 + row) * 2 + 1] = q;
+          }
+        }
+      }
+    if (STATS) {
+      __syncthreads();
+      const int t = threadIdx.x;
+      if (t < MT * 32 && partials) {
+        double sm = 0.0, q = 0.0;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+          sm += (double)red[(w2 * MT * 32 + t) * 2];
+          q += (double)red[(w2 * MT * 32 + t) * 2 + 1];
+        }
+        partials[(size_t)(m0 + t) * NP + p] = sm;
+        partials[((size_t)M + m0 + t) * NP + p] = q;
+      }
+    }
+  } else {
+    float* mine = red + wv * 32 * WV_LD;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * WV_LD + c] = acc[0][r];
+    __syncthreads();
+    constexpr int RPW = 32 / NWK;  // rows finished by each wave (NWK = 2, 4, 8)
+#pragma unroll
+    for (int e = 0; e < RPW / 2; ++e) {
+      const int row = wv * RPW + 2 * e + h;
+      float v = 0.f;
+#pragma unroll
+      for (int j = 0; j < NWK; ++j) v += red[(j * 32 + row) * WV_LD + c];
+      if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
+      if (STATS) {
+        float sm = v, q = v * v;
+#pragma unroll
+        for (int o = 16; o > 0; o >>= 1) {
+          sm += __shfl_xor(sm, o, 64);
+          q += __shfl_xor(q, o, 64);
+        }
+        if (c == 0 && partials) {
+          partials[(size_t)(m0 + row) * NP + p] = (double)sm;
+          partials[((size_t)M + m0 + row) * NP + p] = (double)q;
+        }
+      }
+    }
+  }
+}
+
+// which form runs a (K, M) GEMM: 0 = the LDS-staged kernels above, else KW (NWK = K / KW)
+static inline int wave_form(int K, int M) {
+  if (M % 32 != 0) return 0;
+  if (K == 32) return 32;
+  if (K == 64 || K == 128 || K == 256 || K == 512) return 64;
+  return 0;
+}
+
+template <bool AFFINE, bool STATS, bool TRANS_W>
+static int launch_wave(const float* X, const float* in_scale, const float* in_shift, const float* Wt, float* Y,
+                       double* partials, int N, int M, int K, int S, const msl::BnFold& fold, hipStream_t st) {
+#define MSL_WV(KW_, MT_, NWK_)                                                                                        \
+  hipLaunchKernelGGL((pw_wave_kernel<KW_, MT_, AFFINE, STATS, TRANS_W, NWK_>),                                        \
+                     dim3(msl::cdiv(S, NWK_ == 1 ? 128 : 32), M / (32 * MT_), N), dim3(NWK_ == 1 ? 256 : NWK_ * 64), \
+                     0, st, X, in_scale, in_shift, Wt, Y, partials, M, K, S, fold)
+  const bool two = M % 64 == 0;
+  if (K == 32) {
+    if (two) MSL_WV(32, 2, 1); else MSL_WV(32, 1, 1);
+  } else if (K == 64) {
+    if (two) MSL_WV(64, 2, 1); else MSL_WV(64, 1, 1);
+  } else {
+    switch (K / 64) {
+      case 2: MSL_WV(64, 1, 2); break;
+      case 4: MSL_WV(64, 1, 4); break;
+      case 8: MSL_WV(64, 1, 8); break;
+      default: return MSL_ERR_UNSUPPORTED;
+    }
+  }
+#undef MSL_WV
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
 // bwd-weight.  Block = (k-split, output tile 64 x BNN).  The 4 waves split every 64-position chunk four
 // ways and each keeps the whole tile's accumulators; fixed-order in-block reduction, then one slab per block.
 constexpr int PC = 64, PC_LD = PC + 1;
@@ -467,6 +653,7 @@ static inline bool use_ksplit(int K, int M, int S, int N) {
 }
 
 int msl_pwconv_fwd_num_partials(int N, int Cin, int Cout, int S) {
+  if (wave_form(Cin, Cout)) return N * msl::cdiv(S, Cin <= 64 ? 128 : 32);
   return N * msl::cdiv(S, use_ksplit(Cin, Cout, S, N) ? KS_BN : BN);
 }
 
@@ -478,6 +665,14 @@ static int pwconv_fwd_impl(const float* z, const float* in_scale, const float* i
   if (N <= 0 || S <= 0 || Cin % BK != 0 || Cout % 4 != 0) return MSL_ERR_ARG;
   if ((in_scale || fold.partials) && Cin > FOLD_MAXK) return MSL_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (wave_form(Cin, Cout)) {
+    if (in_scale || fold.partials) {
+      if (partials) return launch_wave<true, true, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, fold, st);
+      return launch_wave<true, false, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, fold, st);
+    }
+    if (partials) return launch_wave<false, true, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, fold, st);
+    return launch_wave<false, false, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, fold, st);
+  }
   if (use_ksplit(Cin, Cout, S, N)) {
     dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cout, KS_BM), N);
 #define MSL_KS(A_, S_, T_, X_, Wp_, Y_, P_, M_, K_)                                                                  \
@@ -534,6 +729,9 @@ int msl_pwconv_fwd_fold(const float* z, const double* in_partials, int in_np, do
 int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,
                         void* stream) {
   if (N <= 0 || S <= 0 || Cout % BK != 0 || Cin % 4 != 0) return MSL_ERR_ARG;
+  if (wave_form(Cout, Cin))
+    return launch_wave<false, false, true>(dy, nullptr, nullptr, w, g_in, nullptr, N, Cin, Cout, S, pw_nofold,
+                                           (hipStream_t)stream);
   if (use_ksplit(Cout, Cin, S, N)) {
     dim3 g2(msl::cdiv(S, KS_BN), msl::cdiv(Cin, KS_BM), N);
     hipStream_t st = (hipStream_t)stream;
