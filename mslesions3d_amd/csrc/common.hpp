@@ -18,16 +18,56 @@
 
 namespace msl {
 
+// ---- cross-lane sums on the VALU (DPP) -------------------------------------------------------------------------
+// __shfl_* lowers to ds_bpermute_b32 (an LDS-pipe instruction per step); a DPP add is one VALU instruction.  The
+// combination order below is fixed, so results stay run-to-run bit-identical.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffll), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xF, 0xF, true);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ float lane_value(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ double lane_value(double v, int lane) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), lane);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Sum over each aligned group of 16 lanes (a DPP "row"); every lane of the group gets the result.
+template <typename T>
+__device__ __forceinline__ T row16_sum(T v) {
+  v += dpp_mov<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_mov<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_mov<0x141>(v);  // row_half_mirror
+  v += dpp_mov<0x140>(v);  // row_mirror
+  return v;
+}
+
+// Sum over each 32-lane half of the wave; valid in lanes 0-15 (lower half) and 32-47 (upper half).
+__device__ __forceinline__ float half32_sum(float v) {
+  v = row16_sum(v);
+  const float a = lane_value(v, 16), b = lane_value(v, 48);
+  return v + ((threadIdx.x & 32) ? b : a);
+}
+
+// Sum over the 64 lanes; every lane gets the result.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;  // lane 0 holds the total
+  v = row16_sum(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-  return v;
+  v = row16_sum(v);
+  return (lane_value(v, 0) + lane_value(v, 16)) + (lane_value(v, 32) + lane_value(v, 48));
 }
 
 // row[col .. col+3] of a row of S floats, zero past the end.  The loads are unconditional on clamped (always valid)

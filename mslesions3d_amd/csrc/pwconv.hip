@@ -414,12 +414,7 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
         const float v = acc[mt][r];
         if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
         if (STATS) {
-          float sm = v, q = v * v;  // columns past S hold exact zeros
-#pragma unroll
-          for (int o = 16; o > 0; o >>= 1) {
-            sm += __shfl_xor(sm, o, 64);
-            q += __shfl_xor(q, o, 64);
-          }
+          const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);  // columns past S hold exact zeros
           if (c == 0) {
             red[(wv * MT * 32 + row) * 2] = sm;
             red[(wv * MT * 32 + row) * 2 + 1] = q;
@@ -454,12 +449,7 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
       for (int j = 0; j < NWK; ++j) v += red[(j * 32 + row) * WV_LD + c];
       if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
       if (STATS) {
-        float sm = v, q = v * v;
-#pragma unroll
-        for (int o = 16; o > 0; o >>= 1) {
-          sm += __shfl_xor(sm, o, 64);
-          q += __shfl_xor(q, o, 64);
-        }
+        const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);
         if (c == 0 && partials) {
           partials[(size_t)(m0 + row) * NP + p] = (double)sm;
           partials[((size_t)M + m0 + row) * NP + p] = (double)q;
