@@ -51,6 +51,10 @@ int msl_bn_relu_bwd_reduce(const float* g, const float* y, const float* scale, c
                            void* stream);
 int msl_bn_bwd_finalize(const double* partials, int num_partials, double count, float* dgamma, float* dbeta,
                         float* c1, float* c2, int C, void* stream);
+/* same on an (8, C) vector block [scale, shift, mean, invstd | c1, c2, cC, cE]: writes rows 4-7, where
+ * dL/dy = scale * gm + (cC * y + cE) is the folded form used by msl_stem_conv_bwd_weight_fused */
+int msl_bn_bwd_finalize_coef(const double* partials, int num_partials, double count, float* dgamma, float* dbeta,
+                             float* bn_vec, int C, void* stream);
 int msl_bn_relu_bwd_apply(const float* g, const float* y, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* c1, const float* c2, float* dy,
                           int N, int C, int S, void* stream);
@@ -72,6 +76,13 @@ int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* 
 int msl_stem_conv_bwd_weight_bnapply(const float* g, const float* yraw, const float* bn_vec, const float* x, float* dw,
                                      float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
                                      void* stream);
+
+/* same again for a stem that feeds a stride-2 depthwise layer with taps w1_t (27,32), tap-major: dz is THAT layer's dL/dz
+ * (N,32,ceil(OD/2),ceil(OH/2),ceil(OW/2)) and the gradient of the stem activation (autograd's grad of ssd3d.py:81's
+ * first feature) is rebuilt from it inside the kernel, never stored.  Pair: msl_dwconv_s2_bwd_bnreduce_bww. */
+int msl_stem_conv_bwd_weight_fused(const float* dz, const float* w1_t, const float* yraw, const float* bn_vec,
+                                   const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
+                                   int sd, int sh, int sw, void* stream);
 
 /* ---- depthwise Conv3d(C,C,k3,stride s,p1,groups=C) : Block.conv1, mobilenet.py:38,44 ---------------------- */
 int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride);
@@ -97,6 +108,16 @@ int msl_dwconv_bwd_data_bnreduce(const float* dy, const float* w, float* g_in, c
                                  const float* bn_scale, const float* bn_shift, const float* bn_mean,
                                  const float* bn_invstd, double* partials, int N, int C, int D, int H, int W, int stride,
                                  int accumulate, void* stream);
+/* stride-2 backward in ONE pass over (dy = dL/dz, y_prev) that does NOT write the input gradient: emits the
+ * BatchNorm-backward partials of the producer layer (fp64 [2][C][NP]) and this layer's weight-gradient partials
+ * (fp64 [C*27][NP]); msl_dwconv_bwd_weight_finalize sums the latter into dw (C,27).  NP from ..._num_partials (-1 =
+ * shape unsupported).  w_taps_t (may be NULL) receives the (27,C) transpose of w. */
+int msl_dwconv_s2_bwd_bnreduce_bww_num_partials(int N, int C, int D, int H, int W);
+int msl_dwconv_s2_bwd_bnreduce_bww(const float* dy, const float* w, const float* y_prev, const float* bn_scale,
+                                   const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                                   double* bn_partials, double* w_partials, float* w_taps_t, int N, int C, int D, int H,
+                                   int W, void* stream);
+int msl_dwconv_bwd_weight_finalize(const double* w_partials, int num_partials, float* dw, int C, void* stream);
 int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream);

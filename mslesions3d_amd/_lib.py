@@ -24,6 +24,7 @@ _SIGNATURES = {
     "msl_bn_relu_bwd_num_partials": (_I, [_I, _I]),
     "msl_bn_relu_bwd_reduce": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_bn_bwd_finalize": (_I, [_P, _I, _D, _P, _P, _P, _P, _I, _P]),
+    "msl_bn_bwd_finalize_coef": (_I, [_P, _I, _D, _P, _P, _P, _I, _P]),
     "msl_bn_relu_bwd_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_bn_relu_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_stem_conv_fwd_num_partials": (_I, [_I, _I, _I, _I]),
@@ -31,6 +32,10 @@ _SIGNATURES = {
     "msl_stem_conv_bwd_weight_workspace_bytes": (_Z, [_I]),
     "msl_stem_conv_bwd_weight": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_stem_conv_bwd_weight_bnapply": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_stem_conv_bwd_weight_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_s2_bwd_bnreduce_bww_num_partials": (_I, [_I, _I, _I, _I, _I]),
+    "msl_dwconv_s2_bwd_bnreduce_bww": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_weight_finalize": (_I, [_P, _I, _P, _I, _P]),
     "msl_dwconv_fwd_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd_variant": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

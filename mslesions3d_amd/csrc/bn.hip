@@ -182,20 +182,45 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
                                                              double count, float* __restrict__ dgamma,
                                                              float* __restrict__ dbeta,
                                                              float* __restrict__ c1, float* __restrict__ c2,
-                                                             int C) {
+                                                             int C, const float* __restrict__ fwd_vec,
+                                                             float* __restrict__ coef) {
   const int c = blockIdx.x, lane = threadIdx.x;
+  const double* ps = partials + (size_t)c * NP;
+  const double* pq = partials + ((size_t)C + c) * NP;
   double s = 0.0, q = 0.0;
-  for (int p = lane; p < NP; p += 64) {
-    s += partials[(size_t)c * NP + p];
-    q += partials[((size_t)C + c) * NP + p];
+  int p = lane;
+  for (; p + 7 * 64 < NP; p += 8 * 64) {  // 16 loads in flight
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = ps[p + u * 64];
+      b[u] = pq[p + u * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s += a[u];
+      q += b[u];
+    }
+  }
+  for (; p < NP; p += 64) {
+    s += ps[p];
+    q += pq[p];
   }
   s = msl::wave_sum(s);
   q = msl::wave_sum(q);
   if (lane == 0) {
     dbeta[c] = (float)s;
     dgamma[c] = (float)q;
-    c1[c] = (float)(s / count);
-    c2[c] = (float)(q / count);
+    const float k1 = (float)(s / count), k2 = (float)(q / count);
+    c1[c] = k1;
+    c2[c] = k2;
+    if (coef) {
+      // dL/dy = scale * (gm - c1 - xhat * c2),  xhat = (y - mean) * invstd   ==   scale * gm + (cC * y + cE)
+      const float sc = fwd_vec[c], mu = fwd_vec[2 * C + c], is = fwd_vec[3 * C + c];
+      const float t = sc * is * k2;
+      coef[c] = -t;
+      coef[C + c] = fmaf(t, mu, -sc * k1);
+    }
   }
 }
 
@@ -460,7 +485,18 @@ int msl_bn_bwd_finalize(const double* partials, int num_partials, double count, 
                         float* c1, float* c2, int C, void* stream) {
   if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
-                     count, dgamma, dbeta, c1, c2, C);
+                     count, dgamma, dbeta, c1, c2, C, (const float*)nullptr, (float*)nullptr);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// Same, on a whole (8, C) BatchNorm vector block [scale, shift, mean, invstd | c1, c2, cC, cE]: rows 4-7 are written;
+// cC, cE fold the backward into  dL/dy = scale * gm + (cC * y + cE)  for consumers that apply it while loading.
+int msl_bn_bwd_finalize_coef(const double* partials, int num_partials, double count, float* dgamma, float* dbeta,
+                             float* bn_vec, int C, void* stream) {
+  if (C <= 0 || num_partials <= 0 || !bn_vec) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
+                     count, dgamma, dbeta, bn_vec + 4 * C, bn_vec + 5 * C, C, (const float*)bn_vec, bn_vec + 6 * C);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

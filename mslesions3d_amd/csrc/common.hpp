@@ -169,14 +169,26 @@ __device__ __forceinline__ void bn_fold_wave(const BnFold& f, int c, float& scal
   const double* ps = f.partials + (size_t)c * f.NP;
   const double* pq = f.partials + ((size_t)f.C + c) * f.NP;
   double s = 0.0, q = 0.0;
-  for (int p = lane; p < f.NP; p += 64) {
+  int p = lane;
+  for (; p + 7 * 64 < f.NP; p += 8 * 64) {  // 16 loads in flight; the additions keep the serial order
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = ps[p + u * 64];
+      b[u] = pq[p + u * 64];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s += a[u];
+      q += b[u];
+    }
+  }
+  for (; p < f.NP; p += 64) {
     s += ps[p];
     q += pq[p];
   }
   s = wave_sum(s);
   q = wave_sum(q);
-  s = __shfl(s, 0, 64);
-  q = __shfl(q, 0, 64);
   bn_affine_from_sums(f, c, s, q, scale, shift, mean_o, invstd_o, var_o);
 }
 

@@ -333,6 +333,130 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stride-2 depthwise backward WITHOUT materialising the input gradient (the 128^3 stem: 134 MB written, then read
+// again by the stem's weight gradient).  One pass over (dL/dz, y_prev) produces everything that needs a full-batch
+// reduction:
+//   * the BatchNorm-backward sums of the producer layer: g = dwconv^T(dL/dz) is formed in registers only to be
+//     folded into  sum gm  and  sum gm * xhat   (gm = g where relu(bn(y_prev)) > 0);
+//   * this layer's weight gradient  dW[c][k] = sum dL/dz[o] * relu(bn(y_prev))[2o-1+k]  - the same (position, tap,
+//     output) triples as g, so it costs one more FMA per triple.
+// The consumer (msl_stem_conv_bwd_weight_fused) rebuilds g from dL/dz on the fly.  Thread = PPT patches of
+// 2 x 2 x 4 input voxels of one (n, c); fixed-order reductions, fp64 partials.
+template <int PPT>
+__global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
+    const float* __restrict__ dy, const float* __restrict__ w, int C, int D, int H, int W, int OD, int OH, int OW,
+    const float* __restrict__ y_prev, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+    const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd, double* __restrict__ bn_partials,
+    double* __restrict__ w_partials, float* __restrict__ w_taps_t) {
+  __shared__ float red[4][32];
+  const int nc = blockIdx.y, c = nc % C;
+  // tap-major copy of the weights, (27, C): the consumer kernel then fetches 8 channels of one tap with one scalar load
+  if (w_taps_t && blockIdx.x == 0 && nc < C && threadIdx.x < 27) w_taps_t[threadIdx.x * C + c] = w[c * 27 + threadIdx.x];
+  const int W4 = W >> 2, H2 = (H + 1) >> 1, D2 = (D + 1) >> 1;
+  const int total = D2 * H2 * W4;
+  float wk[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = w[c * 27 + k];
+  const float sc = bn_scale[c], sh = bn_shift[c], mu = bn_mean[c], is = bn_invstd[c];
+  const float* dyc = dy + (size_t)nc * OD * OH * OW;
+  const float* yc = y_prev + (size_t)nc * D * H * W;
+  float aw[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) aw[k] = 0.f;
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll 1
+  for (int it = 0; it < PPT; ++it) {
+    const int q0 = (blockIdx.x * PPT + it) * 256 + threadIdx.x;
+    const bool live = q0 < total;
+    const int q = live ? q0 : 0;
+    const int cw = q % W4, b = (q / W4) % H2, a = q / (W4 * H2);
+    const int iw0 = cw * 4, c2 = cw * 2;
+    float dv[2][2][3];
+#pragma unroll
+    for (int dd = 0; dd < 2; ++dd)
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh)
+#pragma unroll
+        for (int ww = 0; ww < 3; ++ww) {
+          const bool ok = live && a + dd < OD && b + hh < OH && c2 + ww < OW;
+          const float v = dyc[ok ? ((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww : 0];
+          dv[dd][hh][ww] = ok ? v : 0.f;
+        }
+    bool okp[2][2];
+    float4 yv[2][2];
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const int id = 2 * a + pd, ih = 2 * b + ph;
+        okp[pd][ph] = live && id < D && ih < H;
+        yv[pd][ph] = *reinterpret_cast<const float4*>(yc + (okp[pd][ph] ? ((size_t)id * H + ih) * W + iw0 : 0));
+      }
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) msl::pin(yv[pd][ph]);
+    // per axis: even index -> (offset 0, k = 1); odd index -> (offset 1, k = 0) and (offset 0, k = 2)
+#pragma unroll
+    for (int pd = 0; pd < 2; ++pd)
+#pragma unroll
+      for (int ph = 0; ph < 2; ++ph) {
+        const float ya[4] = {yv[pd][ph].x, yv[pd][ph].y, yv[pd][ph].z, yv[pd][ph].w};
+        float av[4];  // relu(bn(y_prev)) of the 4 voxels; 0 outside the volume
+#pragma unroll
+        for (int k = 0; k < 4; ++k) av[k] = okp[pd][ph] ? msl::act(ya[k], sc, sh) : 0.f;
+        float o0 = 0.f, o1 = 0.f, o2 = 0.f, o3 = 0.f;
+#pragma unroll
+        for (int td = 0; td < (pd ? 2 : 1); ++td) {
+          const int dd = pd ? (td == 0 ? 1 : 0) : 0, kd = pd ? (td == 0 ? 0 : 2) : 1;
+#pragma unroll
+          for (int th = 0; th < (ph ? 2 : 1); ++th) {
+            const int hh = ph ? (th == 0 ? 1 : 0) : 0, kh = ph ? (th == 0 ? 0 : 2) : 1;
+            const int kb = kd * 9 + kh * 3;
+            const float d0 = dv[dd][hh][0], d1 = dv[dd][hh][1], d2 = dv[dd][hh][2];
+            o0 = fmaf(wk[kb + 1], d0, o0);
+            o1 = fmaf(wk[kb], d1, fmaf(wk[kb + 2], d0, o1));
+            o2 = fmaf(wk[kb + 1], d1, o2);
+            o3 = fmaf(wk[kb], d2, fmaf(wk[kb + 2], d1, o3));
+            aw[kb + 1] = fmaf(av[0], d0, fmaf(av[2], d1, aw[kb + 1]));
+            aw[kb] = fmaf(av[1], d1, fmaf(av[3], d2, aw[kb]));
+            aw[kb + 2] = fmaf(av[1], d0, fmaf(av[3], d1, aw[kb + 2]));
+          }
+        }
+        const float ga[4] = {o0, o1, o2, o3};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float gm = av[k] > 0.f ? ga[k] : 0.f;  // av > 0  <=>  inside the volume and relu(bn(y)) > 0
+          s1 += gm;
+          s2 += gm * ((ya[k] - mu) * is);
+        }
+      }
+  }
+  // block reduction of the 27 tap sums and the two BatchNorm sums: DPP wave sums, then the 4 waves in order
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float t = msl::wave_sum(aw[k]);
+    if (lane == 0) red[wv][k] = t;
+  }
+  {
+    const float t1 = msl::wave_sum(s1), t2 = msl::wave_sum(s2);
+    if (lane == 0) {
+      red[wv][27] = t1;
+      red[wv][28] = t2;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 29) {
+    const int k = threadIdx.x;
+    const double t = ((double)red[0][k] + (double)red[1][k]) + ((double)red[2][k] + (double)red[3][k]);
+    const int NP = (gridDim.y / C) * gridDim.x, p = (nc / C) * gridDim.x + blockIdx.x;
+    if (k < 27) w_partials[((size_t)c * 27 + k) * NP + p] = t;
+    else bn_partials[((size_t)(k - 27) * C + c) * NP + p] = t;
+  }
+}
+
 __global__ __launch_bounds__(64) void dw_bwd_weight_finalize_kernel(const double* __restrict__ partials, int NP,
                                                                     float* __restrict__ dw, int count) {
   const int i = blockIdx.x, lane = threadIdx.x;
@@ -430,6 +554,42 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
                      partials, C, D, H, W, OD, OH, OW, stride, chunks, N * chunks, total_items);
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, N * chunks, dw, C * 27);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+constexpr int S2F_PPT = 4;
+
+// Number of fp64 partials per channel (BatchNorm sums) and per (channel, tap) (weight gradient) written by
+// msl_dwconv_s2_bwd_bnreduce_bww; -1 if the shape is not supported.
+int msl_dwconv_s2_bwd_bnreduce_bww_num_partials(int N, int C, int D, int H, int W) {
+  if (W % 4 != 0) return -1;
+  return N * msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT);
+}
+
+// dy = dL/dz (N,C,OD,OH,OW) of a stride-2 depthwise layer, y_prev (N,C,D,H,W) = raw output of the producer layer with
+// its BatchNorm vectors.  Writes bn_partials [2][C][NP] (sum gm, sum gm*xhat of the producer's BatchNorm backward)
+// and w_partials [C*27][NP] (this layer's weight gradient); the input gradient itself is NOT written.
+// w_taps_t (may be NULL): receives the (27, C) transpose of w for msl_stem_conv_bwd_weight_fused.
+int msl_dwconv_s2_bwd_bnreduce_bww(const float* dy, const float* w, const float* y_prev, const float* bn_scale,
+                                   const float* bn_shift, const float* bn_mean, const float* bn_invstd,
+                                   double* bn_partials, double* w_partials, float* w_taps_t, int N, int C, int D, int H,
+                                   int W, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return MSL_ERR_ARG;
+  if (W % 4 != 0) return MSL_ERR_UNSUPPORTED;
+  const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
+  hipLaunchKernelGGL(dw_s2_bwd_reduce_bww_kernel<S2F_PPT>, grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
+                     OH, OW, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, bn_partials, w_partials, w_taps_t);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// dw[c][k] = sum_p w_partials[c*27+k][p]  (fixed order)
+int msl_dwconv_bwd_weight_finalize(const double* w_partials, int num_partials, float* dw, int C, void* stream) {
+  if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, (hipStream_t)stream, w_partials,
+                     num_partials, dw, C * 27);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

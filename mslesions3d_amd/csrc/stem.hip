@@ -8,6 +8,7 @@
 // BN statistics: per-workgroup (sum, sumsq) per channel via an LDS transpose, emitted as fp64 partials.
 #include "common.hpp"
 #include <algorithm>
+#include <type_traits>
 
 namespace {
 
@@ -113,17 +114,31 @@ constexpr int SB_ROW_LD = 131;   // input row pitch (2*64 + 1 = 129 needed; 131 
 // APPLY: `dy` holds dL/d relu(bn(y)) (not yet through the BatchNorm backward); the kernel reads y as well and
 // applies  dL/dy = scale * (gm - c1 - xhat * c2)  while staging the tile, so the 402 MB apply pass over the stem
 // gradient never runs.  bnv = [scale, shift, mean, invstd, c1, c2] x 32 channels.
-template <int CIN, bool APPLY>
+//
+// MODE 2 (FUSED) goes one step further for a stem that feeds a stride-2 depthwise layer: `dy` is that layer's
+// dL/dz (N,32,OD1,OH1,OW1) and w1p its taps, tap-major (27,32); the stem-activation gradient  g = dwconv^T(dL/dz)
+// is rebuilt per chunk, so the 134 MB gradient tensor is neither written nor read.  bnv then has 8 rows
+// [scale, shift, mean, invstd, c1, c2, cC, cE] (msl_bn_bwd_finalize_coef): dL/dy = scale * gm + (cC * y + cE).
+struct StemFusedSrc {
+  int OD1, OH1, OW1;  // dims of dL/dz
+};
+
+template <int CIN, int MODE>
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               float* __restrict__ slabs, int N, int D, int H, int W,
                                                               int OD, int OH, int OW, int sd, int sh, int sw,
                                                               int chunks_per_row, int total_chunks, int iters,
                                                               const float* __restrict__ yraw,
-                                                              const float* __restrict__ bnv) {
+                                                              const float* __restrict__ bnv,
+                                                              const float* __restrict__ w1p, StemFusedSrc fs) {
+  constexpr bool APPLY = MODE >= 1;
+  constexpr bool FUSED = MODE == 2;
   constexpr int NT = (CIN * 27 + 31) / 32;
   constexpr int WAVE_LDS = 32 * SB_DY_LD + CIN * 9 * SB_ROW_LD;
   extern __shared__ __align__(16) float lds[];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // readfirstlane: the wave index (hence the chunk coordinates, the tap parities, every weight address) is wave-uniform,
+  // but only this tells the compiler so - scalar registers, scalar loads and scalar branches instead of vector ones
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   float* dyt = lds + wv * WAVE_LDS;
   float* rows = dyt + 32 * SB_DY_LD;
   const int OS = OD * OH * OW;
@@ -144,6 +159,163 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
 
+  if constexpr (FUSED) {
+    // Software pipeline over (chunk, group of 8 channels): while group k is turned into gradient values, the loads of
+    // group k+1 (8 y + 8 x 4 dz values per lane) are in flight; the next chunk's input rows and first group are
+    // requested before this chunk's MFMAs.  Per axis the voxel index i takes taps
+    //   even i: (k = 1, o = i/2)      odd i: (k = 0, o = (i+1)/2) and (k = 2, o = (i-1)/2)
+    // so a chunk row has 1, 2 or 4 live (kd, kh) pairs (wave-uniform); all four slots are always loaded (dead ones
+    // re-read a live address) and dead slots are skipped with a scalar branch.  Along W lane l loads
+    // dz[(ow >> 1) + (ow & 1)]; an odd voxel takes its kw = 2 tap (dz[ow >> 1]) from its even neighbour by DPP.
+    const int OS1 = fs.OD1 * fs.OH1 * fs.OW1;
+    struct Ctx {
+      bool live, in, okl, odd;   // in/okl/odd: per lane
+      bool vD[2], vH[2];         // wave-uniform from here on
+      int kD[2], kH[2];
+      int n, od, oh, ow0;
+      int ly, ldz;               // per-lane element offsets into a y row / a dz row
+      const float* yrow;         // y_raw at (n, 0, od, oh, ow0)
+      const float* dzrow[4];     // dz rows of the four (td, th) slots at (n, 0, ., ., 0)
+    };
+    auto make_ctx = [&](int it) {
+      Ctx c;
+      const int chunk = (blockIdx.x * iters + it) * 4 + wv;
+      c.live = it < iters && chunk < total_chunks;
+      const int cc = c.live ? chunk : 0;
+      const int seg = cc % chunks_per_row;
+      int r = cc / chunks_per_row;
+      c.oh = r % OH;
+      r /= OH;
+      c.od = r % OD;
+      c.n = r / OD;
+      c.ow0 = seg * 64;
+      const int npos = c.live ? min(64, OW - c.ow0) : 0;
+      c.in = lane < npos;
+      c.ly = c.in ? lane : 0;
+      const int ow = c.ow0 + c.ly;
+      c.odd = ow & 1;
+      const int jl = (ow >> 1) + (ow & 1);
+      c.okl = jl < fs.OW1;
+      c.ldz = c.okl ? jl : 0;
+      const bool pd = c.od & 1, ph = c.oh & 1;
+      int idD[2], idH[2];
+      idD[0] = pd ? (c.od + 1) >> 1 : c.od >> 1; c.kD[0] = pd ? 0 : 1; c.vD[0] = idD[0] < fs.OD1;
+      idD[1] = c.od >> 1;                         c.kD[1] = 2;          c.vD[1] = pd;
+      idH[0] = ph ? (c.oh + 1) >> 1 : c.oh >> 1; c.kH[0] = ph ? 0 : 1; c.vH[0] = idH[0] < fs.OH1;
+      idH[1] = c.oh >> 1;                         c.kH[1] = 2;          c.vH[1] = ph;
+      if (!c.vD[0]) idD[0] = c.od >> 1;  // dead slots re-read a live row
+      if (!c.vH[0]) idH[0] = c.oh >> 1;
+      c.yrow = yraw + (size_t)c.n * 32 * OS + ((size_t)c.od * OH + c.oh) * OW + c.ow0;
+      const float* dzn = dy + (size_t)c.n * 32 * OS1;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) c.dzrow[t] = dzn + ((size_t)idD[t >> 1] * fs.OH1 + idH[t & 1]) * fs.OW1;
+      return c;
+    };
+    // every address is (wave-uniform row pointer)[per-lane int offset]
+    auto issue = [&](const Ctx& c, int cg, float (&yv)[8], float (&dz)[8][4]) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) yv[k] = (c.yrow + (size_t)(cg * 8 + k) * OS)[c.ly];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) dz[k][t] = (c.dzrow[t] + (size_t)(cg * 8 + k) * OS1)[c.ldz];
+    };
+    auto consume = [&](const Ctx& c, int cg, const float (&yv)[8], const float (&dz)[8][4]) {
+      float g[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) g[k] = 0.f;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (c.vD[t >> 1] && c.vH[t & 1]) {  // wave-uniform
+          const float* wk = w1p + (c.kD[t >> 1] * 9 + c.kH[t & 1] * 3) * 32 + cg * 8;  // tap-major (27, 32)
+          float dn[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) dn[k] = msl::dpp_mov<0xA0>(dz[k][t]);  // quad_perm [0,0,2,2]: the even neighbour's dz
+          // the taps are scalar operands; the lane classes are execution masks, not selects:
+          //   even voxel: kw = 1 on its own dz;  odd voxel: kw = 2 on the neighbour's, kw = 0 on its own (if in range)
+          if (c.odd) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = fmaf(wk[64 + k], dn[k], g[k]);
+            if (c.okl) {
+#pragma unroll
+              for (int k = 0; k < 8; ++k) g[k] = fmaf(wk[k], dz[k][t], g[k]);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) g[k] = fmaf(wk[32 + k], dz[k][t], g[k]);
+          }
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int co = cg * 8 + k;
+        const float sc = bnv[co], sf = bnv[32 + co];
+        const float gm = fmaf(yv[k], sc, sf) > 0.f ? g[k] : 0.f;
+        const float v = fmaf(sc, gm, fmaf(bnv[192 + co], yv[k], bnv[224 + co]));  // scale*gm + (cC*y + cE)
+        dyt[co * SB_DY_LD + lane] = c.in ? v : 0.f;
+      }
+    };
+    float xreg[CIN * 9][3];
+    bool xok[CIN * 9][3];
+    auto issue_x = [&](const Ctx& c) {
+      const int iw0 = c.ow0 * sw - 1;
+      const int span = 64 * sw + 1;
+#pragma unroll
+      for (int ci = 0; ci < CIN; ++ci)
+#pragma unroll
+        for (int rr = 0; rr < 9; ++rr) {
+          const int id = c.od * sd - 1 + rr / 3, ih = c.oh * sh - 1 + rr % 3;
+          const bool rok = c.live && id >= 0 && id < D && ih >= 0 && ih < H;
+          const float* src = x + (((size_t)c.n * CIN + ci) * D + (rok ? id : 0)) * H * W + (size_t)(rok ? ih : 0) * W;
+#pragma unroll
+          for (int t = 0; t < 3; ++t) {
+            const int j = lane + 64 * t, iw = iw0 + j;
+            xok[ci * 9 + rr][t] = rok && j <= span && iw >= 0 && iw < W;
+            xreg[ci * 9 + rr][t] = src[xok[ci * 9 + rr][t] ? iw : 0];
+          }
+        }
+    };
+    float ya[8], da[8][4], yb[8], db[8][4];
+    Ctx cur = make_ctx(0);
+    issue_x(cur);
+    issue(cur, 0, ya, da);
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+      for (int r2 = 0; r2 < CIN * 9; ++r2)
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          float v = xok[r2][t] ? xreg[r2][t] : 0.f;
+          if (t == 2) msl::pin(v);  // else the load is sunk into the conditional store
+          const int j = lane + 64 * t;
+          if (j < SB_ROW_LD) rows[r2 * SB_ROW_LD + j] = v;
+        }
+      issue(cur, 1, yb, db);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(cur, 0, ya, da);
+      issue(cur, 2, ya, da);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(cur, 1, yb, db);
+      issue(cur, 3, yb, db);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(cur, 2, ya, da);
+      const Ctx nxt = make_ctx(it + 1);
+      issue_x(nxt);
+      issue(nxt, 0, ya, da);
+      __builtin_amdgcn_sched_barrier(0);
+      consume(cur, 3, yb, db);
+#pragma unroll 4
+      for (int s = 0; s < 32; ++s) {
+        const int pos = 2 * s + (lane >> 5);
+        const float a = dyt[(lane & 31) * SB_DY_LD + pos];
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float b = tapoff[nt] >= 0 ? rows[tapoff[nt] + pos * sw] : 0.f;
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
+        }
+      }
+      cur = nxt;
+    }
+  } else
   for (int it = 0; it < iters; ++it) {
     const int chunk = (blockIdx.x * iters + it) * 4 + wv;
     const bool live = chunk < total_chunks;
@@ -155,7 +327,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     const int od = r % OD, n = r / OD;
     const int ow0 = seg * 64;
     const int npos = live ? min(64, OW - ow0) : 0;
-    __syncthreads();  // previous chunk's LDS reads are done
+    // (the tiles are private to the wave and a wave's LDS operations execute in order: no barrier in this loop)
     // Issue every global load of the chunk first (32 dy + 9*CIN*3 input values per lane in flight), then
     // store to LDS: a load->store->load chain would expose the full memory latency 59 times per chunk.
     // Every load is unconditional on a clamped (always valid) address and masked afterwards: a predicated load
@@ -222,7 +394,6 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
         const int j = lane + 64 * t;
         if (j < SB_ROW_LD) rows[r2 * SB_ROW_LD + j] = xreg[r2][t];
       }
-    __syncthreads();
 #pragma unroll 4
     for (int s = 0; s < 32; ++s) {
       const int pos = 2 * s + (lane >> 5);
@@ -311,11 +482,22 @@ size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin) {
 
 // dw (32,Cin,3,3,3) = correlation of dy (N,32,OD,OH,OW) with x (N,Cin,D,H,W)
 static int stem_bww_impl(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
-                         int sd, int sh, int sw, const float* yraw, const float* bnv, void* stream);
+                         int sd, int sh, int sw, const float* yraw, const float* bnv, const float* w1, void* stream);
 
 int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D,
                              int H, int W, int sd, int sh, int sw, void* stream) {
-  return stem_bww_impl(dy, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, nullptr, nullptr, stream);
+  return stem_bww_impl(dy, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, nullptr, nullptr, nullptr, stream);
+}
+
+// The stem feeds a stride-2 depthwise layer (taps w1_t (27,32), tap-major as written by
+// msl_dwconv_s2_bwd_bnreduce_bww) and `dz` is THAT layer's dL/dz (N,32,ceil(OD/2),ceil(OH/2),ceil(OW/2)): the
+// gradient of the stem activation is rebuilt from dz inside the kernel.  bn_vec: the (8,32) block of
+// msl_bn_bwd_finalize_coef.
+int msl_stem_conv_bwd_weight_fused(const float* dz, const float* w1_t, const float* yraw, const float* bn_vec,
+                                   const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
+                                   int sd, int sh, int sw, void* stream) {
+  if (!dz || !w1_t || !yraw || !bn_vec) return MSL_ERR_ARG;
+  return stem_bww_impl(dz, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, yraw, bn_vec, w1_t, stream);
 }
 
 // g = dL/d relu(bn(y)): BatchNorm backward applied on load.  bn_vec = (6, 32) fp32 rows [scale, shift, mean, invstd,
@@ -324,11 +506,11 @@ int msl_stem_conv_bwd_weight_bnapply(const float* g, const float* yraw, const fl
                                      float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
                                      void* stream) {
   if (!yraw || !bn_vec) return MSL_ERR_ARG;
-  return stem_bww_impl(g, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, yraw, bn_vec, stream);
+  return stem_bww_impl(g, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, yraw, bn_vec, nullptr, stream);
 }
 
 static int stem_bww_impl(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
-                         int sd, int sh, int sw, const float* yraw, const float* bnv, void* stream) {
+                         int sd, int sh, int sw, const float* yraw, const float* bnv, const float* w1, void* stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || sd < 1 || sd > 2 || sh < 1 || sh > 2 || sw < 1 || sw > 2)
     return MSL_ERR_ARG;
   const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
@@ -339,6 +521,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
   hipStream_t st = (hipStream_t)stream;
   const int NT = (Cin * 27 + 31) / 32;
   const size_t lds = (size_t)4 * (32 * SB_DY_LD + Cin * 9 * SB_ROW_LD) * sizeof(float);
+  const StemFusedSrc fs{(OD - 1) / 2 + 1, (OH - 1) / 2 + 1, (OW - 1) / 2 + 1};
 #define MSL_STEM_BW1(CI, AP)                                                                                         \
   do {                                                                                                               \
     if (lds > 64 * 1024) {                                                                                           \
@@ -347,12 +530,13 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
       if (e_ != hipSuccess) return (int)e_;                                                                          \
     }                                                                                                                \
     hipLaunchKernelGGL((stem_bwd_weight_kernel<CI, AP>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, D,  \
-                       H, W, OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters, yraw, bnv);                \
+                       H, W, OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters, yraw, bnv, w1, fs);        \
   } while (0)
-#define MSL_STEM_BW(CI)            \
-  do {                             \
-    if (yraw) MSL_STEM_BW1(CI, true); \
-    else MSL_STEM_BW1(CI, false);  \
+#define MSL_STEM_BW(CI)                 \
+  do {                                  \
+    if (w1) MSL_STEM_BW1(CI, 2);        \
+    else if (yraw) MSL_STEM_BW1(CI, 1); \
+    else MSL_STEM_BW1(CI, 0);           \
   } while (0)
   switch (Cin) {
     case 1: MSL_STEM_BW(1); break;

@@ -16,7 +16,7 @@ import torch
 from . import _lib
 from ._lib import ptr
 
-BN_ROWS = 6  # scale, shift, mean, invstd, c1, c2
+BN_ROWS = 8  # scale, shift, mean, invstd, c1, c2, cC, cE (the last two: msl_bn_bwd_finalize_coef)
 
 
 def conv_out(d, s):
@@ -183,6 +183,16 @@ class Plan:
             # private scratch of the weight-gradient stream (its kernels overlap the main stream's)
             self.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
             self.partials_w = torch.empty_like(self.partials)
+            # fused stem backward (block 1 is a stride-2 depthwise layer fed by a 32-channel stem that is not a head
+            # feature): its dL/d(stem activation) is never materialised (Engine.backward)
+            self.fused_stem_np = -1
+            if (len(specs) > 1 and specs[0]["cout"] == 32 and specs[1]["cin"] == 32 and tuple(specs[1]["stride"]) == (2, 2, 2)
+                    and 0 not in self.feat_ids):
+                np_f = L.msl_dwconv_s2_bwd_bnreduce_bww_num_partials(N, 32, *self.dims[0])
+                if np_f > 0 and 2 * 32 * np_f <= self.partials.numel():
+                    self.fused_stem_np = np_f
+                    self.partials_wf = torch.empty(32 * 27 * np_f, dtype=torch.float64, device=device)
+                    self.w1_taps_t = torch.empty((27, 32), **f32)
         self.events = {}
         self.saved_input = None
         self.generation = 0
@@ -203,6 +213,7 @@ class Engine:
         # finalize launches from the forward chain, but every workgroup then re-reads the partials: measured on
         # MI355X it costs each consumer what the launch saved (depthwise block 1: 40 -> 49 us) — off by default.
         self.fold_bn = False
+        self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
         self.side = {}
         self.arena = None
         self.plans = {}
@@ -452,12 +463,16 @@ class Engine:
                 ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
 
     # ------------------------------------------------------------------------------------------------
-    def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st, pre_np=None, apply=True):
+    def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st, pre_np=None, apply=True, coef=False):
         """In place: g (= dL/d relu(bn(y))) becomes dL/dy; writes dgamma/dbeta into the gradient arena.
         ``pre_np``: the producer of g already emitted the reduce partials (pl.partials, that many per channel);
         ``apply=False``: the consumer applies the BatchNorm backward itself while loading (only c1/c2 are produced)."""
         L = _lib.load()
         gv = self.arena.grad_views
+        if pre_np is not None and coef:
+            _lib.call("msl_bn_bwd_finalize_coef", ptr(pl.partials), pre_np, float(count), ptr(gv[bn_name + ".weight"]),
+                      ptr(gv[bn_name + ".bias"]), ptr(vec), C, st)
+            return
         if pre_np is not None:
             _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), pre_np, float(count), ptr(gv[bn_name + ".weight"]),
                       ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
@@ -576,7 +591,18 @@ class Engine:
             # big producer layers: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
             Sp = pd * ph * pw
             np_red = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, sp["cin"], pd, ph, pw) if (s == 2 and N * Sp > 65536) else -1
-            if np_red > 0 and 2 * sp["cin"] * np_red <= pl.partials.numel():
+            fused_stem = i == 1 and self.fuse_stem and pl.fused_stem_np > 0
+            ev_red = None
+            if fused_stem:
+                # one pass over (dL/dz_1, y_0): BatchNorm-backward sums of the stem + the depthwise weight gradient;
+                # the stem weight gradient below rebuilds dL/d(stem activation) from dL/dz_1 on the fly
+                vp = pl.bn_y[0]
+                self._k("dw_bwd1", "msl_dwconv_s2_bwd_bnreduce_bww", ptr(pl.g_z[1]), ptr(feats[1].conv1.weight), ptr(pl.y[0]),
+                        ptr(vp[0]), ptr(vp[1]), ptr(vp[2]), ptr(vp[3]), ptr(pl.partials), ptr(pl.partials_wf), ptr(pl.w1_taps_t),
+                        N, 32, pd, ph, pw, st)
+                pre_np = pl.fused_stem_np
+                ev_red = self._record(pl, "dz1_reduced", st) if ms else None
+            elif np_red > 0 and 2 * sp["cin"] * np_red <= pl.partials.numel():
                 vp = pl.bn_y[i - 1]
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bnreduce", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight),
                         ptr(pl.g_y[i - 1]), ptr(pl.y[i - 1]), ptr(vp[0]), ptr(vp[1]), ptr(vp[2]), ptr(vp[3]), ptr(pl.partials),
@@ -585,11 +611,17 @@ class Engine:
             else:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
-            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz):
+            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red):
                 if ms:  # one event per layer: both weight gradients start once dL/dz_i is final
                     self._wait(stW, ev_dz)
                 self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
                         ptr(pl.bn_z[i][1]), ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, stW)
+                if fused_stem:
+                    if ms:
+                        self._wait(stW, ev_red)
+                    self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_finalize", ptr(pl.partials_wf), pl.fused_stem_np,
+                            ptr(gv[name + ".conv1.weight"]), sp["cin"], stW)
+                    return
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
                         ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w if ms else pl.partials),
                         N, sp["cin"], pd, ph, pw, s, stW)
@@ -612,11 +644,17 @@ class Engine:
         sd, sh, sw = specs[0]["stride"]
         if pre_np is not None and specs[0]["cout"] == 32:
             # reduce came with the depthwise bwd-data above; the apply is fused into the stem weight gradient
+            fused = self.fuse_stem and pl.fused_stem_np > 0
             self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, 32, S0, pl, st, pre_np=pre_np,
-                         apply=False)
-            self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(pl.bn_y[0]),
-                    ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W,
-                    sd, sh, sw, st)
+                         apply=False, coef=fused)
+            if fused:
+                self._k("stem_bww", "msl_stem_conv_bwd_weight_fused", ptr(pl.g_z[1]), ptr(pl.w1_taps_t), ptr(pl.y[0]),
+                        ptr(pl.bn_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N,
+                        specs[0]["cin"], D, H, W, sd, sh, sw, st)
+            else:
+                self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(pl.bn_y[0]),
+                        ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W,
+                        sd, sh, sw, st)
         else:
             self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st,
                          pre_np=pre_np)

@@ -193,6 +193,53 @@ def test_fused_bn_backward_of_the_stem_tail():
     close(dw, w0.grad, 2e-4, 1e-4, "stem dW with fused BN apply")
 
 
+@pytest.mark.parametrize("cin,dims", [(1, (12, 16, 24)), (2, (16, 16, 16)), (1, (10, 14, 72))])
+def test_stem_backward_without_materialising_the_activation_gradient(cin, dims):
+    """One pass over (dL/dz_1, y_0) for the BatchNorm sums and the depthwise weight gradient, then the stem weight
+    gradient rebuilding dL/d(stem activation) from dL/dz_1 on the fly == CPU autograd through
+    conv -> BN -> ReLU -> depthwise conv (odd output sizes included: 5 x 7 x 36 from 10 x 14 x 72)."""
+    L = _lib.load()
+    N = 2
+    x = rnd(N, cin, *dims, seed=1)
+    w0 = rnd(32, cin, 3, 3, 3, seed=2, scale=0.3).requires_grad_(True)
+    gamma = (rnd(32, seed=3).abs() + 0.5).requires_grad_(True)
+    beta = rnd(32, seed=4, scale=0.2).requires_grad_(True)
+    w1 = rnd(32, 1, 3, 3, 3, seed=5, scale=0.4).requires_grad_(True)
+    y0 = F.conv3d(x, w0, stride=2, padding=1)
+    a0 = torch.relu(F.batch_norm(y0, None, None, gamma, beta, True, 0.1, 1e-5))
+    z1 = F.conv3d(a0, w1, stride=2, padding=1, groups=32)
+    dz = rnd(*z1.shape, seed=6)
+    z1.backward(dz)
+    od, oh, ow = y0.shape[2:]
+    S0 = od * oh * ow
+    yd = y0.detach().double()
+    part = torch.stack([yd.sum((0, 2, 3, 4)), (yd ** 2).sum((0, 2, 3, 4))]).view(2, 32, 1).contiguous().to(DEV)
+    vec = torch.zeros((8, 32), device=DEV)
+    _lib.call("msl_bn_finalize", ptr(part), 1, float(N * S0), ptr(K(gamma)), ptr(K(beta)), None, None, None, 0.1, 1e-5,
+              ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, st())
+    NP = L.msl_dwconv_s2_bwd_bnreduce_bww_num_partials(N, 32, od, oh, ow)
+    assert NP > 0
+    bp = torch.full((2 * 32 * NP,), float("nan"), dtype=torch.float64, device=DEV)
+    wp = torch.full((32 * 27 * NP,), float("nan"), dtype=torch.float64, device=DEV)
+    y0d, dzd, w1d = K(y0), K(dz), K(w1)
+    w1t = torch.full((27, 32), float("nan"), device=DEV)
+    _lib.call("msl_dwconv_s2_bwd_bnreduce_bww", ptr(dzd), ptr(w1d), ptr(y0d), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+              ptr(vec[3]), ptr(bp), ptr(wp), ptr(w1t), N, 32, od, oh, ow, st())
+    assert torch.equal(w1t.cpu(), w1.detach().view(32, 27).t())
+    dgam, dbet = torch.empty(32, device=DEV), torch.empty(32, device=DEV)
+    _lib.call("msl_bn_bwd_finalize_coef", ptr(bp), NP, float(N * S0), ptr(dgam), ptr(dbet), ptr(vec), 32, st())
+    close(dgam, gamma.grad, 1e-4, 1e-5, "dgamma")
+    close(dbet, beta.grad, 1e-4, 1e-5, "dbeta")
+    dw1 = torch.empty((32, 1, 3, 3, 3), device=DEV)
+    _lib.call("msl_dwconv_bwd_weight_finalize", ptr(wp), NP, ptr(dw1), 32, st())
+    close(dw1, w1.grad, 1e-4, 1e-4, "depthwise dW from the fused pass")
+    dw = torch.empty((32, cin, 3, 3, 3), device=DEV)
+    ws = torch.empty(L.msl_stem_conv_bwd_weight_workspace_bytes(cin) // 4, device=DEV)
+    _lib.call("msl_stem_conv_bwd_weight_fused", ptr(dzd), ptr(w1t), ptr(y0d), ptr(vec), ptr(K(x)), ptr(dw), ptr(ws), N, cin,
+              *dims, 2, 2, 2, st())
+    close(dw, w0.grad, 2e-4, 1e-4, "stem dW with the gradient rebuilt on the fly")
+
+
 # ------------------------------------------------------------------------------------------------- pointwise
 @pytest.mark.parametrize("N,Cin,Cout,S", [(2, 32, 64, 1000), (1, 64, 128, 64), (2, 128, 128, 130), (1, 512, 512, 8),
                                           (1, 256, 512, 27)])

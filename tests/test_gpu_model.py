@@ -262,6 +262,31 @@ def test_in_kernel_bn_fold_is_bit_identical():
         assert torch.equal(a, b)
 
 
+def test_fused_stem_backward_matches_the_materialised_path():
+    """Engine.fuse_stem (default): block 1's backward never stores dL/d(stem activation).  Every gradient agrees with
+    the path that materialises it, within fp32 reduction-order noise."""
+    size, n = (64, 64, 64), 2
+    x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, n, size)
+    outs = []
+    for fuse in (False, True):
+        m = hip_model(1, size)
+        m._engine.fuse_stem = fuse
+        m.train()
+        l, s = m(x)
+        c, lc = m.loss_fn(l, s, [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels])
+        (c + lc).backward()
+        assert m._engine.plan_for(x, True).fused_stem_np > 0
+        outs.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert outs[0].keys() == outs[1].keys()
+    for k in outs[0]:
+        a, b = outs[0][k], outs[1][k]
+        assert torch.allclose(a, b, rtol=2e-4, atol=1e-5 * float(a.abs().max()) + 1e-8), k
+    # only the stem and block 1's depthwise taps and the stem BatchNorm take the other route
+    same = [k for k in outs[0] if torch.equal(outs[0][k], outs[1][k])]
+    assert "base.features.2.conv1.weight" in same and "pred_convs.loc_convs.0.weight" in same
+
+
 def test_determinism_run_to_run():
     size, n = (64, 64, 64), 2
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
