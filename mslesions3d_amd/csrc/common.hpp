@@ -155,7 +155,21 @@ __device__ __forceinline__ void bn_fold_serial(const BnFold& f, int c, float& sc
   const double* ps = f.partials + (size_t)c * f.NP;
   const double* pq = f.partials + ((size_t)f.C + c) * f.NP;
   double s = 0.0, q = 0.0;
-  for (int p = 0; p < f.NP; ++p) {
+  int p = 0;
+  for (; p + 8 <= f.NP; p += 8) {  // 16 loads in flight; the additions keep the serial order
+    double a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      a[u] = ps[p + u];
+      b[u] = pq[p + u];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      s += a[u];
+      q += b[u];
+    }
+  }
+  for (; p < f.NP; ++p) {
     s += ps[p];
     q += pq[p];
   }

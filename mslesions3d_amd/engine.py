@@ -11,6 +11,8 @@ Data convention: conv kernels write RAW outputs + fp64 statistic partials; ``msl
 a per-channel (scale, shift); the next kernel applies relu(x*scale+shift) while loading.  Only the three
 feature maps the heads read are materialised (in a zero-haloed layout).
 """
+import os
+
 import torch
 
 from . import _lib
@@ -212,7 +214,9 @@ class Engine:
         # Folding the BatchNorm statistics inside the consumer kernels (csrc/common.hpp BnFold) removes the 15
         # finalize launches from the forward chain, but every workgroup then re-reads the partials: measured on
         # MI355X it costs each consumer what the launch saved (depthwise block 1: 40 -> 49 us) — off by default.
-        self.fold_bn = False
+        self.fold_bn = False     # fold EVERY BatchNorm into its consumers (slower: big layers have thousands of partials)
+        # default: fold only the BatchNorms with at most this many partials per channel (tuning knob: MSL_FOLD_NP_MAX)
+        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "32"))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
         self.side = {}
         self.arena = None
@@ -345,7 +349,8 @@ class Engine:
         specs = self.layer_specs
         _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
 
-        fold = training and self.fold_bn
+        fold_max = (1 << 30) if self.fold_bn else self.fold_np_max
+        folds = lambda NP: training and NP <= fold_max  # is the BatchNorm with NP partials folded into its consumers?
         deferred = []
         bn_layers = []  # (bn module, vector buffer, partials, NP, element count) of every BatchNorm, in order
 
@@ -366,10 +371,13 @@ class Engine:
         self._k("stem_fwd", "msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]),
                 ptr(pl.part_y[0]) if training else None, N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         od, oh, ow = pl.dims[0]
-        if fold:
-            finalize_later(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], N * od * oh * ow, "stat_y0")
-        else:
-            self._bn_fwd(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], N * od * oh * ow, training, st)
+        def bn_done(bn, vec, part, NP, count, name):
+            if folds(NP):
+                finalize_later(bn, vec, part, NP, count, name)
+            else:
+                self._bn_fwd(bn, vec, part, NP, count, training, st)
+
+        bn_done(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], N * od * oh * ow, "stat_y0")
         out_feats = {}
         for i in range(1, len(specs)):
             sp, blk = specs[i], feats[i]
@@ -378,32 +386,32 @@ class Engine:
             S = D * H * W
             s = sp["stride"][0]
             bn_prev = feats[0][1] if i == 1 else feats[i - 1].bn2
-            if fold:
+            if folds(pl.np_y[i - 1]):
                 self._k(f"dw_fwd{i}", "msl_dwconv_fwd_fold", ptr(pl.y[i - 1]), ptr(pl.part_y[i - 1]), pl.np_y[i - 1],
                         float(N * pd * ph * pw), ptr(bn_prev.weight), ptr(bn_prev.bias), bn_prev.eps, ptr(blk.conv1.weight),
                         ptr(pl.z[i]), ptr(pl.part_z[i]), N, sp["cin"], pd, ph, pw, s, st)
-                flush()
-                finalize_later(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, f"stat_z{i}")
-                self._k(f"pw_fwd{i}", "msl_pwconv_fwd_fold", ptr(pl.z[i]), ptr(pl.part_z[i]), pl.np_z[i], float(N * S),
-                        ptr(blk.bn1.weight), ptr(blk.bn1.bias), blk.bn1.eps, ptr(blk.conv2.weight), ptr(pl.y[i]),
-                        ptr(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
-                flush()
-                finalize_later(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, f"stat_y{i}")
             else:
                 self._k(f"dw_fwd{i}", "msl_dwconv_fwd", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
                         ptr(blk.conv1.weight), ptr(pl.z[i]), ptr(pl.part_z[i]) if training else None, N, sp["cin"], pd, ph,
                         pw, s, 0, st)
-                self._bn_fwd(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, training, st)
+            flush()
+            bn_done(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, f"stat_z{i}")
+            if folds(pl.np_z[i]):
+                self._k(f"pw_fwd{i}", "msl_pwconv_fwd_fold", ptr(pl.z[i]), ptr(pl.part_z[i]), pl.np_z[i], float(N * S),
+                        ptr(blk.bn1.weight), ptr(blk.bn1.bias), blk.bn1.eps, ptr(blk.conv2.weight), ptr(pl.y[i]),
+                        ptr(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
+            else:
                 self._k(f"pw_fwd{i}", "msl_pwconv_fwd", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
                         ptr(blk.conv2.weight), ptr(pl.y[i]), ptr(pl.part_y[i]) if training else None, N, sp["cin"],
                         sp["cout"], S, st)
-                self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, training, st)
+            flush()
+            bn_done(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, f"stat_y{i}")
             if i in pl.fpad:
                 plain = None
                 if want_features:
                     plain = torch.empty((N, sp["cout"], D, H, W), dtype=torch.float32, device=x.device)
                     out_feats[i] = plain
-                if fold:
+                if folds(pl.np_y[i]):
                     self._k(f"materialize{i}", "msl_bn_relu_materialize_fold", ptr(pl.y[i]), ptr(pl.part_y[i]), pl.np_y[i],
                             float(N * S), ptr(blk.bn2.weight), ptr(blk.bn2.bias), blk.bn2.eps, ptr(plain), ptr(pl.fpad[i]),
                             N, sp["cout"], D, H, W, st)
@@ -418,8 +426,11 @@ class Engine:
                 else:
                     self._head_forward(pl, i, st)
         flush()
-        if fold:
-            self._finalize_all(pl, bn_layers, st)
+        if bn_layers:
+            # running statistics and backward vectors of the folded BatchNorms: one launch, beside the last head
+            if self.multi_stream:
+                self._fork(pl, "fwd_stats_ready", st, stH)
+            self._finalize_all(pl, bn_layers, stH)
         if self.multi_stream:
             self._fork(pl, "fwd_heads_done", stH, st)
         if nan_check:  # the fused training step lets the loss kernel set the flag instead (it reads both tensors anyway)

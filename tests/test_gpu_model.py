@@ -248,9 +248,9 @@ def test_in_kernel_bn_fold_is_bit_identical():
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
     boxes, labels = detinit.make_gt(8, n, size)
     outs = []
-    for fold in (False, True):
+    for fold, np_max in ((False, 0), (False, 32), (True, 32)):  # never / small layers only (default) / always
         m = hip_model(1, size)
-        m._engine.fold_bn = fold
+        m._engine.fold_bn, m._engine.fold_np_max = fold, np_max
         m.train()
         l, s = m(x)
         c, lc = m.loss_fn(l, s, [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels])
@@ -258,8 +258,9 @@ def test_in_kernel_bn_fold_is_bit_identical():
         sd = m.state_dict()
         outs.append((l.clone(), s.clone(), torch.cat([p.grad.reshape(-1) for p in m.parameters() if p.grad is not None]),
                      sd["base.features.5.bn2.running_var"].clone(), sd["base.features.0.1.running_mean"].clone()))
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
 
 
 def test_fused_stem_backward_matches_the_materialised_path():
