@@ -74,9 +74,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # MSL_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share devices;
+    # functional check only - the driver's scaling run uses RCCL, one rank per GPU)
+    backend = os.environ.get("MSL_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -139,6 +146,14 @@ def main():
     eng.check_nan(pl)
     conf, loc, npos = model.loss_fn._state(args.batch, pl.P, 2, 0, dev)["loss_out"].tolist()
     assert conf == conf and loc == loc and npos > 0, (conf, loc, npos)
+    if world > 1:
+        # data-parallel invariant (outside the timed region): every replica holds the same parameters
+        flat = model._engine.arena.flat
+        ref = flat.detach().clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1.0 if torch.equal(ref, flat) else 0.0], device=dev)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        assert float(same.item()) == 1.0, "replicas diverged: the gradient all-reduce is not reaching every parameter"
 
     if rank == 0:
         value = world * args.batch * args.steps / dt
