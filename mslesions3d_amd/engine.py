@@ -256,7 +256,8 @@ class Engine:
         """(heads, wgrad) torch streams for ``device`` (created once)."""
         key = (device.type, device.index)
         if key not in self.side:
-            self.side[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+            pr = int(os.environ.get("MSL_SIDE_STREAM_PRIORITY", "0"))
+            self.side[key] = (torch.cuda.Stream(device=device, priority=pr), torch.cuda.Stream(device=device, priority=pr))
         return self.side[key]
 
     @staticmethod
@@ -427,10 +428,9 @@ class Engine:
                     self._head_forward(pl, i, st)
         flush()
         if bn_layers:
-            # running statistics and backward vectors of the folded BatchNorms: one launch, beside the last head
-            if self.multi_stream:
-                self._fork(pl, "fwd_stats_ready", st, stH)
-            self._finalize_all(pl, bn_layers, stH)
+            # running statistics and backward vectors of the folded BatchNorms: one launch on the MAIN stream (a hop to
+            # a side stream and back costs two cross-queue hand-offs of ~16 us each, tools/bench_launch.py)
+            self._finalize_all(pl, bn_layers, st)
         if self.multi_stream:
             self._fork(pl, "fwd_heads_done", stH, st)
         if nan_check:  # the fused training step lets the loss kernel set the flag instead (it reads both tensors anyway)
@@ -515,7 +515,7 @@ class Engine:
             self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), pl.N, C, D, H, W, ncls, st)
             if data_done_event is not None:  # the activation-gradient chain only waits for the data gradient
                 _lib.call("msl_event_record", data_done_event, st, tag="event")
-        if not weight:
+        if not weight or os.environ.get("MSL_DEBUG_SKIP_WGRAD") == "1":
             return
         self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
                 ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
@@ -623,6 +623,8 @@ class Engine:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
             def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red):
+                if os.environ.get("MSL_DEBUG_SKIP_WGRAD") == "1":  # timing experiment: results are wrong
+                    return
                 if ms:  # one event per layer: both weight gradients start once dL/dz_i is final
                     self._wait(stW, ev_dz)
                 self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),

@@ -7,6 +7,8 @@ MultiBox loss -> closed-form loss gradient -> backward -> (RCCL bucketed all-red
 (ssd3d.py:467-531 + :704-722).  ``LSSD3D.training_step`` + ``loss.backward()`` + ``optimizer.step()`` is the
 API-compatible (autograd) route through the same kernels.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -79,7 +81,8 @@ class FusedTrainer:
         arena = eng.ensure_arena(dev)
         red = self._reducer(arena)
         if self._stream is None or self._stream.device != dev:
-            self._stream = torch.cuda.Stream(device=dev)
+            # high priority: the dependency chain must not queue behind the bulk weight-gradient work of the side streams
+            self._stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MSL_MAIN_STREAM_PRIORITY", "-1")))
         caller = torch.cuda.current_stream(dev)
         self._stream.wait_stream(caller)  # inputs produced on the caller's stream
         with torch.cuda.stream(self._stream):
