@@ -89,6 +89,22 @@ __device__ __forceinline__ float4 load4_zfill(const float* __restrict__ row, int
   return v;
 }
 
+// Scalar-base addressing.  A pointer that IS wave-uniform is made so for the compiler too (two v_readfirstlane) and kept
+// in the GLOBAL address space (an integer round trip would otherwise yield a generic pointer and flat_* instructions);
+// base + zero-extended 32-bit BYTE offset then selects the saddr mode: no 64-bit vector address arithmetic per access.
+typedef __attribute__((address_space(1))) char gbyte;
+__device__ __forceinline__ gbyte* uniform_base(const void* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (gbyte*)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ float load_f32(const gbyte* base, unsigned byte_off) {
+  return *(const __attribute__((address_space(1))) float*)(base + byte_off);
+}
+__device__ __forceinline__ void store_f32(gbyte* base, unsigned byte_off, float v) {
+  *(__attribute__((address_space(1))) float*)(base + byte_off) = v;
+}
+
 // Force a loaded value into its register HERE.  Without it the optimiser sinks a load into the conditional block
 // that is its only user, which turns "issue U loads, then use them" back into U serial round trips.
 __device__ __forceinline__ void pin(float& v) { asm volatile("" : "+v"(v)); }

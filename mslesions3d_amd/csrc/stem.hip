@@ -13,6 +13,7 @@
 namespace {
 
 constexpr int STEM_COUT = 32;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 template <int CIN>
 __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__ x,
@@ -101,13 +102,183 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 
 
 // ---------------------------------------------------------------------------------------------
+// Stem forward on the matrix cores.  The VALU form above spends 27*Cin FMAs per output and channel (864 per voxel at
+// Cin = 1): 23 us of pure VALU issue at 128^3 x 4 next to a 34 us HBM floor.  As a GEMM  Y[32 x pos] = W[32 x K] .
+// im2col[K x pos]  (K = 27*Cin, padded to even) on v_mfma_f32_32x32x2_f32 the same work is 12 us of MFMA time and the
+// kernel becomes a streaming one.  A wave owns 64 consecutive outputs of one row (two 32-column tiles):
+//   A operand  lane (h, c): W[c][2kk + h]                               - registers, loaded once per wave
+//   B operand  lane (h, c): x at tap k = 2kk + h of output column c     - one global load per kk, straight to registers
+// (interior tiles take a mask-free path; volume borders a clamped-and-masked one).  Per-channel (sum, sumsq) are
+// carried per lane across the wave's chunks and reduced once at the end (DPP), fp64 partials [2][32][NP].
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            float* __restrict__ y, double* __restrict__ partials,
+                                                            int D, int H, int W, int OD, int OH, int OW, int sd, int sh,
+                                                            int sw, int chunks_per_row, int chunks_per_n, int iters) {
+  constexpr int K = CIN * 27, KS = (K + 1) / 2;
+  __shared__ float red[4][2][32];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c = lane & 31;
+  const int n = blockIdx.y;
+  const int OS = OD * OH * OW;
+  const float* xn = x + (size_t)n * CIN * D * H * W;
+  float* yn = y + (size_t)n * STEM_COUT * OS;
+
+  float wa[KS];
+  int tapoff[KS];  // element offset of the lane's tap kk inside the image
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 2 * kk + h;
+    const bool vk = k < K;
+    const int ci = k / 27, t = k % 27, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    wa[kk] = vk ? w[c * K + (vk ? k : 0)] : 0.f;
+    tapoff[kk] = vk ? ((ci * D + kd) * H + kh) * W + kw : 0;
+  }
+  float ssum[16], qsum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ssum[r] = qsum[r] = 0.f;
+  // Buffer addressing for the streaming accesses: address = descriptor base + per-lane 32-bit byte offset (VGPR, fixed
+  // for the whole kernel) + per-tile scalar byte offset (SGPR) - nothing per access runs on the vector ALU.
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)msl::uniform_base(xn), 0, (int)((unsigned)CIN * D * H * W * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)msl::uniform_base(yn), 0, (int)((unsigned)STEM_COUT * OS * 4u), 0x00020000);
+  int lanetap4[KS];  // byte offset of (tap kk, column c) relative to the tile's first tap
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) lanetap4[kk] = (c * sw + tapoff[kk]) * 4;
+
+  // The wave walks `iters` consecutive 64-column chunks = 2 * iters tiles of 32 output columns; the im2col column of
+  // tile j+1 is requested before the MFMAs of tile j, so loads, matrix work and stores of consecutive tiles overlap.
+  // Everything per tile is kept off the VALU as far as possible (it is the VALU, not the matrix pipe or HBM, that
+  // bounds a naive version: ~450 vector instructions per tile against 14 MFMAs): tile coordinates advance with scalar
+  // increments, addresses are (scalar base)[unsigned 32-bit lane offset].
+  struct Tile {
+    bool live;
+    int od, oh, seg, half;  // wave-uniform
+  };
+  Tile cur;
+  {
+    const int chunk0 = (blockIdx.x * 4 + wv) * iters;
+    cur.live = chunk0 < chunks_per_n;
+    const int cc = cur.live ? chunk0 : 0;
+    cur.seg = cc % chunks_per_row;
+    const int r0 = cc / chunks_per_row;
+    cur.oh = r0 % OH;
+    cur.od = r0 / OH;
+    cur.half = 0;
+  }
+  int tiles_left = 2 * iters;  // of this wave
+  auto advance = [&](Tile t) {  // the next tile of the walk
+    --tiles_left;
+    if (t.half == 0) {
+      t.half = 1;
+    } else {
+      t.half = 0;
+      if (++t.seg == chunks_per_row) {
+        t.seg = 0;
+        if (++t.oh == OH) {
+          t.oh = 0;
+          ++t.od;
+        }
+      }
+    }
+    t.live = t.live && tiles_left > 0 && t.od < OD;  // once past the end (or never started) a wave stays idle
+    if (!t.live) t.od = t.oh = t.seg = 0;
+    return t;
+  };
+  auto load_tile = [&](const Tile& t, float (&b)[KS]) {
+    const int owt = t.seg * 64 + t.half * 32;
+    const int id0 = t.od * sd - 1, ih0 = t.oh * sh - 1;
+    const int rowbase = (id0 * H + ih0) * W - 1;
+    const int ow = owt + c;
+    const bool rows_in = id0 >= 0 && id0 + 2 < D && ih0 >= 0 && ih0 + 2 < H;
+    if (t.live && rows_in && owt >= 1 && (owt + 31) * sw + 1 < W) {  // wave-uniform: every tap of every lane is inside
+      const int soff = __builtin_amdgcn_readfirstlane((rowbase + owt * sw) * 4);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) b[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, lanetap4[kk], soff, 0));
+    } else {
+      const bool pv = t.live && ow < OW;
+      const int iw0 = ow * sw - 1;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const int k = 2 * kk + h, t27 = k % 27, kd = t27 / 9, kh = (t27 / 3) % 3, kw = t27 % 3;
+        const int id = id0 + kd, ih = ih0 + kh, iw = iw0 + kw;
+        const bool ok = pv && k < K && id >= 0 && id < D && ih >= 0 && ih < H && iw >= 0 && iw < W;
+        const float v = xn[ok ? rowbase + ow * sw + tapoff[kk] : 0];
+        b[kk] = ok ? v : 0.f;
+      }
+    }
+  };
+  const int loff4 = (4 * h * OS + c) * 4;  // per lane, bytes: rows 4h.., column c
+  auto finish_tile = [&](const Tile& t, const float (&b)[KS]) {
+    f32x16 acc = {0};
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kk], b[kk], acc, 0, 0, 0);
+    // D[row][col]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int owt = t.seg * 64 + t.half * 32;
+    const int yoff = __builtin_amdgcn_readfirstlane(((t.od * OH + t.oh) * OW + owt) * 4);  // scalar
+    if (t.live && owt + 32 <= OW) {  // wave-uniform: whole tile inside
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), ry, loff4, yoff + ((r & 3) + 8 * (r >> 2)) * OS * 4, 0);
+    } else {
+      const bool pv = t.live && owt + c < OW;
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (pv) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), ry, loff4, yoff + ((r & 3) + 8 * (r >> 2)) * OS * 4, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float v = acc[r];  // exact zero in dead columns (their im2col column is zero)
+      ssum[r] += v;
+      qsum[r] = fmaf(v, v, qsum[r]);
+    }
+  };
+  {
+    float b0[KS], b1[KS];
+    load_tile(cur, b0);
+    while (tiles_left > 0) {  // wave-uniform
+      const Tile t1 = advance(cur);
+      load_tile(t1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      finish_tile(cur, b0);
+      cur = advance(t1);
+      load_tile(cur, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      finish_tile(t1, b1);
+    }
+  }
+  if (partials) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float s = msl::half32_sum(ssum[r]), q = msl::half32_sum(qsum[r]);
+      if (c == 0) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[wv][0][row] = s;
+        red[wv][1][row] = q;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int ch = threadIdx.x;
+      const double s = ((double)red[0][0][ch] + (double)red[1][0][ch]) + ((double)red[2][0][ch] + (double)red[3][0][ch]);
+      const double q = ((double)red[0][1][ch] + (double)red[1][1][ch]) + ((double)red[2][1][ch] + (double)red[3][1][ch]);
+      const int NP = gridDim.x * gridDim.y, p = n * gridDim.x + blockIdx.x;
+      partials[(size_t)ch * NP + p] = s;
+      partials[((size_t)STEM_COUT + ch) * NP + p] = q;
+    }
+  }
+}
+
+constexpr int STEM_FWD_BLOCKS_PER_IMAGE = 256;
+
+// ---------------------------------------------------------------------------------------------
 // Stem bwd-weight: dW[co][k] = sum_{n,o} dy[n,co,o] * x[n,ci,o*s-1+tap], k = ci*27 + tap.
 // A GEMM with M = 32 (co), N = 27*Cin (k, padded to 32*NT), K = all output positions (1M at 128^3 x 4), on
 // v_mfma_f32_32x32x2_f32.  Each wave walks chunks of <= 64 consecutive outputs of one output row: the dy tile
 // (32 x 64, coalesced along W) and the 9*Cin input rows it needs are staged in the wave's own LDS region;
 // the im2col operand is gathered from those rows (row pitch == 3 mod 32 -> the 27 taps hit distinct banks).
 // The read of dy (134 MB) dominates; accumulators stay in registers over all chunks of a wave.
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int SB_DY_LD = 65;     // dy tile pitch
 constexpr int SB_ROW_LD = 131;   // input row pitch (2*64 + 1 = 129 needed; 131 % 32 == 3)
 
@@ -454,23 +625,35 @@ constexpr int STEM_BW_BLOCKS = 512;
 
 extern "C" {
 
-int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW) { return N * msl::cdiv(OD * OH * OW, 256); }
+static inline int stem_fwd_blocks(int OD, int OH, int OW) {
+  return std::min(STEM_FWD_BLOCKS_PER_IMAGE, msl::cdiv(OD * OH * msl::cdiv(OW, 64), 4));
+}
+
+int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW) { return N * stem_fwd_blocks(OD, OH, OW); }
 
 // x (N,Cin,D,H,W) -> y (N,32,OD,OH,OW) raw conv output + fp64 stat partials [2][32][NP].
 int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D,
                       int H, int W, int sd, int sh, int sw, void* stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || sd < 1 || sd > 2 || sh < 1 || sh > 2 || sw < 1 || sw > 2)
     return MSL_ERR_ARG;
+  if ((long long)Cin * D * H * W >= (1ll << 30)) return MSL_ERR_UNSUPPORTED;  // in-image byte offsets are 32-bit
   const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
-  dim3 grid(msl::cdiv(OD * OH * OW, 256), N);
+  const int chunks_per_row = msl::cdiv(OW, 64), chunks_per_n = OD * OH * chunks_per_row;
+  const int nb = stem_fwd_blocks(OD, OH, OW);
+  const int iters = msl::cdiv(chunks_per_n, nb * 4);
+  dim3 grid(nb, N);
   hipStream_t st = (hipStream_t)stream;
+#define MSL_STEM_FW(CI)                                                                                              \
+  hipLaunchKernelGGL(stem_fwd_mfma_kernel<CI>, grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, sh, \
+                     sw, chunks_per_row, chunks_per_n, iters)
   switch (Cin) {
-    case 1: hipLaunchKernelGGL(stem_fwd_kernel<1>, grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, sh, sw); break;
-    case 2: hipLaunchKernelGGL(stem_fwd_kernel<2>, grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, sh, sw); break;
-    case 3: hipLaunchKernelGGL(stem_fwd_kernel<3>, grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, sh, sw); break;
-    case 4: hipLaunchKernelGGL(stem_fwd_kernel<4>, grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, sh, sw); break;
+    case 1: MSL_STEM_FW(1); break;
+    case 2: MSL_STEM_FW(2); break;
+    case 3: MSL_STEM_FW(3); break;
+    case 4: MSL_STEM_FW(4); break;
     default: return MSL_ERR_UNSUPPORTED;
   }
+#undef MSL_STEM_FW
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

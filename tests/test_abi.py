@@ -56,7 +56,7 @@ def test_pure_host_entry_points():
     lib = _lib.load()
     assert lib.msl_abi_version() == 1
     # shape planning helpers are host-only arithmetic: config A (128^3, batch 4) of BASELINE.json
-    assert lib.msl_stem_conv_fwd_num_partials(4, 64, 64, 64) == 4 * 1024
+    assert lib.msl_stem_conv_fwd_num_partials(4, 64, 64, 64) == 4 * 256
     assert lib.msl_dwconv_fwd_variant(4, 32, 64, 64, 64, 2) == 1   # L1: streamed planes
     assert lib.msl_dwconv_fwd_variant(4, 64, 32, 32, 32, 2) == 2   # L2: LDS-resident slab
     assert lib.msl_dwconv_fwd_variant(2, 512, 2, 2, 2, 1) == 0     # 64^3 config tail: generic kernel
