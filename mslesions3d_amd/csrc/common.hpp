@@ -52,11 +52,13 @@ __device__ __forceinline__ T row16_sum(T v) {
   return v;
 }
 
-// Sum over each 32-lane half of the wave; valid in lanes 0-15 (lower half) and 32-47 (upper half).
+// Sum over each 32-lane half of the wave; valid in lanes 16-31 (lower half) and 48-63 (upper half): the second
+// 16-lane row of each half adds the first row's total, broadcast from its lane 15 (row_bcast15 - 5 VALU instructions).
+constexpr int HALF32_SUM_LANE = 16;  // (lane & 31) of a lane that holds the result
 __device__ __forceinline__ float half32_sum(float v) {
   v = row16_sum(v);
-  const float a = lane_value(v, 16), b = lane_value(v, 48);
-  return v + ((threadIdx.x & 32) ? b : a);
+  const float prev = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x142, 0xA, 0xF, false));
+  return v + prev;
 }
 
 // Sum over the 64 lanes; every lane gets the result.

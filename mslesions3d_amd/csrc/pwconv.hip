@@ -415,7 +415,7 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
         if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
         if (STATS) {
           const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);  // columns past S hold exact zeros
-          if (c == 0) {
+          if (c == msl::HALF32_SUM_LANE) {
             red[(wv * MT * 32 + row) * 2] = sm;
             red[(wv * MT * 32 + row) * 2 + 1] = q;
           }
@@ -450,7 +450,7 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
       if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
       if (STATS) {
         const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);
-        if (c == 0 && partials) {
+        if (c == msl::HALF32_SUM_LANE && partials) {
           partials[(size_t)(m0 + row) * NP + p] = (double)sm;
           partials[((size_t)M + m0 + row) * NP + p] = (double)q;
         }

@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float s = msl::half32_sum(ssum[r]), q = msl::half32_sum(qsum[r]);
-      if (c == 0) {
+      if (c == msl::HALF32_SUM_LANE) {
         const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
         red[wv][0][row] = s;
         red[wv][1][row] = q;
@@ -344,10 +344,18 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
       bool vD[2], vH[2];         // wave-uniform from here on
       int kD[2], kH[2];
       int n, od, oh, ow0;
-      int ly, ldz;               // per-lane element offsets into a y row / a dz row
-      const float* yrow;         // y_raw at (n, 0, od, oh, ow0)
-      const float* dzrow[4];     // dz rows of the four (td, th) slots at (n, 0, ., ., 0)
+      int ly4, ldz4;             // per-lane BYTE offsets into a y row / a dz row
+      unsigned yrow4;            // byte offset of y_raw (n, 0, od, oh, ow0)
+      unsigned dzrow4[4];        // byte offsets of the dz rows of the four (td, th) slots at (n, 0, ., ., 0)
     };
+    // Buffer addressing: descriptor base + per-lane VGPR byte offset + scalar byte offset.  The 160 loads of a chunk then
+    // need one 32-bit scalar add each instead of a 64-bit pointer computation (the kernel was bound by its SCALAR
+    // instruction stream: ~1000 scalar instructions per chunk, most of them address arithmetic).
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)msl::uniform_base(yraw), 0, (int)((unsigned)N * 32u * (unsigned)OS * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)msl::uniform_base(dy), 0, (int)((unsigned)N * 32u * (unsigned)OS1 * 4u), 0x00020000);
+    const unsigned OS4 = (unsigned)OS * 4u, OS14 = (unsigned)OS1 * 4u;
     auto make_ctx = [&](int it) {
       Ctx c;
       const int chunk = (blockIdx.x * iters + it) * 4 + wv;
@@ -362,12 +370,13 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
       c.ow0 = seg * 64;
       const int npos = c.live ? min(64, OW - c.ow0) : 0;
       c.in = lane < npos;
-      c.ly = c.in ? lane : 0;
-      const int ow = c.ow0 + c.ly;
+      const int ly = c.in ? lane : 0;
+      c.ly4 = ly * 4;
+      const int ow = c.ow0 + ly;
       c.odd = ow & 1;
       const int jl = (ow >> 1) + (ow & 1);
       c.okl = jl < fs.OW1;
-      c.ldz = c.okl ? jl : 0;
+      c.ldz4 = (c.okl ? jl : 0) * 4;
       const bool pd = c.od & 1, ph = c.oh & 1;
       int idD[2], idH[2];
       idD[0] = pd ? (c.od + 1) >> 1 : c.od >> 1; c.kD[0] = pd ? 0 : 1; c.vD[0] = idD[0] < fs.OD1;
@@ -376,20 +385,24 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
       idH[1] = c.oh >> 1;                         c.kH[1] = 2;          c.vH[1] = ph;
       if (!c.vD[0]) idD[0] = c.od >> 1;  // dead slots re-read a live row
       if (!c.vH[0]) idH[0] = c.oh >> 1;
-      c.yrow = yraw + (size_t)c.n * 32 * OS + ((size_t)c.od * OH + c.oh) * OW + c.ow0;
-      const float* dzn = dy + (size_t)c.n * 32 * OS1;
+      c.yrow4 = ((unsigned)(c.n * 32) * (unsigned)OS + (unsigned)((c.od * OH + c.oh) * OW + c.ow0)) * 4u;
+      const unsigned dzn = (unsigned)(c.n * 32) * (unsigned)OS1;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) c.dzrow[t] = dzn + ((size_t)idD[t >> 1] * fs.OH1 + idH[t & 1]) * fs.OW1;
+      for (int t = 0; t < 4; ++t) c.dzrow4[t] = (dzn + (unsigned)((idD[t >> 1] * fs.OH1 + idH[t & 1]) * fs.OW1)) * 4u;
       return c;
     };
-    // every address is (wave-uniform row pointer)[per-lane int offset]
     auto issue = [&](const Ctx& c, int cg, float (&yv)[8], float (&dz)[8][4]) {
+      unsigned o = c.yrow4 + (unsigned)(cg * 8) * OS4;  // scalar, advanced by one channel per load
 #pragma unroll
-      for (int k = 0; k < 8; ++k) yv[k] = (c.yrow + (size_t)(cg * 8 + k) * OS)[c.ly];
+      for (int k = 0; k < 8; ++k, o += OS4)
+        yv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, c.ly4, (int)o, 0));
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
+        unsigned q = c.dzrow4[t] + (unsigned)(cg * 8) * OS14;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) dz[k][t] = (c.dzrow[t] + (size_t)(cg * 8 + k) * OS1)[c.ldz];
+        for (int k = 0; k < 8; ++k, q += OS14)
+          dz[k][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, c.ldz4, (int)q, 0));
+      }
     };
     auto consume = [&](const Ctx& c, int cg, const float (&yv)[8], const float (&dz)[8][4]) {
       float g[8];
@@ -680,6 +693,10 @@ int msl_stem_conv_bwd_weight_fused(const float* dz, const float* w1_t, const flo
                                    const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
                                    int sd, int sh, int sw, void* stream) {
   if (!dz || !w1_t || !yraw || !bn_vec) return MSL_ERR_ARG;
+  {  // the kernel addresses y and dz with 32-bit byte offsets
+    const long long OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
+    if ((long long)N * 32 * OD * OH * OW * 4 >= (1ll << 32)) return MSL_ERR_UNSUPPORTED;
+  }
   return stem_bww_impl(dz, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, yraw, bn_vec, w1_t, stream);
 }
 

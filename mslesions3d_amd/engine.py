@@ -191,7 +191,8 @@ class Plan:
             if (len(specs) > 1 and specs[0]["cout"] == 32 and specs[1]["cin"] == 32 and tuple(specs[1]["stride"]) == (2, 2, 2)
                     and 0 not in self.feat_ids):
                 np_f = L.msl_dwconv_s2_bwd_bnreduce_bww_num_partials(N, 32, *self.dims[0])
-                if np_f > 0 and 2 * 32 * np_f <= self.partials.numel():
+                small = self.y[0].numel() * 4 < (1 << 32)  # the fused kernel uses 32-bit byte offsets
+                if np_f > 0 and small and 2 * 32 * np_f <= self.partials.numel():
                     self.fused_stem_np = np_f
                     self.partials_wf = torch.empty(32 * 27 * np_f, dtype=torch.float64, device=device)
                     self.w1_taps_t = torch.empty((27, 32), **f32)

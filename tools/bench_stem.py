@@ -33,4 +33,18 @@ def timeit(fn, reps=50):
 
 t = timeit(lambda: _lib.call("msl_stem_conv_fwd", ptr(x), ptr(w), ptr(y), ptr(part), N, 1, D, D, D, 2, 2, 2, st))
 mb = 4e-6 * (x.numel() + y.numel())
-print(f"stem fwd (MSL_STEM_DEBUG={os.environ.get('MSL_STEM_DEBUG', '0')}): {t:.1f} us, {mb:.0f} MB -> {mb / t * 1e-6 * 1e6 / 1e6:.2f} TB/s")
+print(f"stem fwd: {t:.1f} us, {mb:.0f} MB -> {mb / t:.2f} TB/s (x is cache-resident here: one buffer)")
+
+# fused stem backward (kernel B): dz (N,32,32^3), tap-major w1, y raw, 8-row BN vector block
+dz = torch.randn(N, 32, D // 4, D // 4, D // 4, device="cuda")
+w1t = torch.randn(27, 32, device="cuda")
+vec = torch.rand(8, 32, device="cuda") + 0.5
+dw = torch.empty(32, 27, device="cuda")
+ws = torch.empty(L.msl_stem_conv_bwd_weight_workspace_bytes(1) // 4, device="cuda")
+t = timeit(lambda: _lib.call("msl_stem_conv_bwd_weight_fused", ptr(dz), ptr(w1t), ptr(y), ptr(vec), ptr(x), ptr(dw), ptr(ws),
+                             N, 1, D, D, D, 2, 2, 2, st))
+print(f"stem bwd-weight fused: {t:.1f} us")
+g = torch.randn_like(y)
+t = timeit(lambda: _lib.call("msl_stem_conv_bwd_weight_bnapply", ptr(g), ptr(y), ptr(vec), ptr(x), ptr(dw), ptr(ws),
+                             N, 1, D, D, D, 2, 2, 2, st))
+print(f"stem bwd-weight bnapply (materialised gradient): {t:.1f} us")
