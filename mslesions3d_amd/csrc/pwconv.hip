@@ -626,7 +626,12 @@ BwPlan bw_plan(int N, int Cin, int Cout, int S) {
   p.chunks_per_img = msl::cdiv(S, PC);
   const int total = N * p.chunks_per_img;
   const int tiles = (Cout / 64) * (Cin / p.bnn);
+  // K split: enough workgroups to matter, but at least 8 position chunks each - every split costs a Cout x Cin slab
+  // written and read back (a 256-way split of block 2 moved 8 MB of slabs for 12 MB of operands), and this kernel
+  // runs on the weight-gradient stream beside the dependency chain, where fewer, longer workgroups interfere less
   int ks = std::max(1, std::min(total, 512 / std::max(1, tiles)));
+  static const int min_cpb = getenv("MSL_PW_BWW_MIN_CPB") ? atoi(getenv("MSL_PW_BWW_MIN_CPB")) : 1;
+  ks = std::max(1, std::min(ks, total / std::max(1, min_cpb)));
   p.chunks_per_block = msl::cdiv(total, ks);
   p.ksplit = msl::cdiv(total, p.chunks_per_block);
   return p;
