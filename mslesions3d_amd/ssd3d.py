@@ -264,6 +264,8 @@ class LSSD3D(nn.Module):
         self._engine = Engine(self)
         self._param_names = [n for n, _ in self.named_parameters()]
         self._det_ws = {}
+        self._pred_programs = {}
+        self.use_predict_programs = True  # predict_step replays a recorded launch program (see _predict_replay)
 
         # Prior boxes (ssd3d.py:244).  The draw below keeps RNG parity with the reference's third dummy pass.
         self.base.get_feature_map_infos(self.input_size, self.device)
@@ -402,10 +404,18 @@ class LSSD3D(nn.Module):
         locs = predicted_locs.detach().contiguous().float()
         scores = predicted_scores.detach().contiguous().float()
         w = self._detect_workspace(N, P, ncls, int(top_k), locs.device)
+        self._detect_launch(locs, scores, w, min_score, max_overlap, top_k)
+        return self._detect_collect(w, N, return_prior_index)
+
+    def _detect_launch(self, locs, scores, w, min_score, max_overlap, top_k):
+        N, P, ncls = locs.size(0), locs.size(1), scores.size(2)
         _lib.call("msl_detect_objects", ptr(locs), ptr(scores), ptr(self.priors_cxcycz), N, P, ncls, float(min_score),
                   float(max_overlap), int(top_k), ptr(w["probs"]), ptr(w["boxes"]), ptr(w["sorted_idx"]), ptr(w["ncand"]),
                   ptr(w["mask"]), ptr(w["keep"]), ptr(w["nkept"]), ptr(w["tmp_s"]), ptr(w["tmp_r"]), ptr(w["ob"]),
                   ptr(w["os"]), ptr(w["ol"]), ptr(w["op"]), ptr(w["oc"]), _stream())
+
+    @staticmethod
+    def _detect_collect(w, N, return_prior_index=False):
         counts = w["oc"].tolist()  # the only host sync
         boxes = [w["ob"][i, :counts[i]].clone() for i in range(N)]
         labels = [w["ol"][i, :counts[i]].clone() for i in range(N)]
@@ -484,9 +494,41 @@ class LSSD3D(nn.Module):
     def predict_step(self, batch, batch_idx: int = 0, dataloader_idx: int = None):
         """ssd3d.py:692-702."""
         with torch.no_grad():
+            if self.use_predict_programs and not self.training:
+                return self._predict_replay(batch["img"])
             predicted_locs, predicted_scores = self(batch["img"].to(self.device))
             return self.detect_objects(predicted_locs, predicted_scores, min_score=self.min_score,
                                        max_overlap=self.max_overlap, top_k=self.top_k)
+
+    def _predict_replay(self, img):
+        """predict_step without Python between the launches: the first batch of a shape runs eval forward + decode + NMS
+        through the executor and records its C-ABI calls on a persistent input buffer; later batches are copied into that
+        buffer and the launch program is replayed natively (same kernels, same arguments).  One host sync per batch."""
+        dev = self.device
+        x = img.to(dev, non_blocking=True).contiguous().float()
+        self._ensure_device_state(dev)
+        eng = self._engine
+        eng.ensure_arena(dev)
+        key = (tuple(x.shape), _stream(), float(self.min_score), float(self.max_overlap), int(self.top_k), id(eng.arena))
+        ent = self._pred_programs.get(key)
+        if ent is None:
+            buf = torch.empty_like(x)
+            buf.copy_(x)
+            _lib.start_recording()
+            try:
+                locs, scores = eng.forward(buf, training=False, need_grad=False)
+                w = self._detect_workspace(locs.size(0), locs.size(1), scores.size(2), int(self.top_k), dev)
+                self._detect_launch(locs, scores, w, self.min_score, self.max_overlap, self.top_k)
+            finally:
+                prog = _lib.stop_recording()
+            ent = self._pred_programs[key] = {"buf": buf, "ws": w, "plan": eng.plan_for(buf, False),
+                                              "compiled": _lib.compile_program(prog, set())}
+        else:
+            ent["buf"].copy_(x)
+            _lib.replay_native(ent["compiled"], None)
+        out = self._detect_collect(ent["ws"], x.size(0))
+        eng.check_nan(ent["plan"])  # the queue is already drained: no second wait
+        return out
 
     def configure_optimizers(self):
         """ssd3d.py:704-722: Adam(weight_decay 5e-4), '.bias' parameters at 2*lr, cosine annealing T_max=40."""

@@ -368,6 +368,55 @@ def test_nms_keep_list_bit_exact_on_shared_probabilities():
         assert torch.equal(l[i].cpu(), ol[i])
 
 
+def test_inference_192_end_to_end_matches_the_oracle():
+    """BASELINE configs[3] shape (192^3, batch 2, fp32): eval forward -> decode -> 3-D NMS on 31 536 priors against the CPU
+    oracle with the same weights: locs / scores within 1e-4, keep-lists (prior indices, order) bit-exact."""
+    from oracle.network import OracleSSD3D
+    size, n = (192, 192, 192), 2
+    m = hip_model(1, size).eval()
+    x = detinit.make_volume_batch(9, n, 1, size)
+    with torch.no_grad():
+        locs, scores = m(x.to(DEV))
+        b, l, s, pi = m.detect_objects(locs, scores, 0.3, 0.3, 50, return_prior_index=True)
+    om = OracleSSD3D(2, 1, size, emulate_reference_init=False)
+    om.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()})
+    om.eval()
+    with torch.no_grad():
+        ol, osc = om(x)
+        ob, olab, oscore, oi = OD.detect_objects(ol, osc, om.priors_cxcycz, 0.3, 0.3, 50, return_prior_index=True)
+    assert locs.shape[1] == 31536
+    assert_close(locs, ol, RTOL, "192^3 locs")
+    assert_close(scores, osc, RTOL, "192^3 scores")
+    for i in range(n):
+        assert torch.equal(pi[i].cpu(), oi[i]) and torch.equal(l[i].cpu(), olab[i])
+        if len(ob[i]):
+            assert float((b[i].cpu() - ob[i]).abs().max()) <= 1e-4
+
+
+def test_predict_step_replay_equals_the_eager_path():
+    """predict_step replays a recorded launch program from the second batch of a shape on: same detections as the
+    Python-driven path, batch after batch, also after the weights and running statistics have changed."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (64, 64, 64), 2
+    m = hip_model(1, size, min_score=0.3, max_overlap=0.3, top_k=20)
+    boxes, labels = detinit.make_gt(8, n, size)
+    tr = FusedTrainer(m)
+    for rnd_ in range(2):
+        m.eval()
+        for seed in (11, 12, 13):
+            batch = {"img": detinit.make_volume_batch(seed, n, 1, size)}
+            m.use_predict_programs = True
+            fast = m.predict_step(batch)
+            m.use_predict_programs = False
+            slow = m.predict_step(batch)
+            for a, b in zip(fast, slow):
+                for u, v in zip(a, b):
+                    assert torch.equal(u, v)
+        assert len(m._pred_programs) == 1
+        m.train()
+        tr.step(detinit.make_volume_batch(5, n, 1, size).to(DEV), [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels])
+
+
 def test_training_validation_predict_steps():
     size, n = (64, 64, 64), 2  # P = 1168 > 500 so mAP is computed (ssd3d.py:504)
     m = hip_model(1, size, lr=1e-3, min_score=0.3)
