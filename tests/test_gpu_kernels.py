@@ -198,6 +198,10 @@ def test_stem_backward_without_materialising_the_activation_gradient(cin, dims):
     """One pass over (dL/dz_1, y_0) for the BatchNorm sums and the depthwise weight gradient, then the stem weight
     gradient rebuilding dL/d(stem activation) from dL/dz_1 on the fly == CPU autograd through
     conv -> BN -> ReLU -> depthwise conv (odd output sizes included: 5 x 7 x 36 from 10 x 14 x 72)."""
+    _fused_stem_case(cin, dims)
+
+
+def _fused_stem_case(cin, dims):
     L = _lib.load()
     N = 2
     x = rnd(N, cin, *dims, seed=1)
@@ -408,3 +412,68 @@ def test_nan_flag():
     x[77777] = float("nan")
     _lib.call("msl_nan_flag", ptr(x), x.numel(), ptr(flag), 2, st())
     assert int(flag) == 2
+
+
+# ------------------------------------------------------------------------------------------------- random shapes
+def _rng_shapes(seed, n, gen):
+    import random
+    r = random.Random(seed)
+    return [gen(r) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _rng_shapes(101, 8, lambda r: (r.choice([1, 2, 3]), r.choice([32, 64, 128, 256, 512]),
+                                                                r.choice([32, 64, 128, 256]), r.randint(1, 300))),
+                         ids=lambda c: "N%d_K%d_M%d_S%d" % c)
+def test_pw_random_shapes(case):
+    """Wave-autonomous pointwise kernels at seeded random (N, Cin, Cout, S): ragged column counts, every K-split width."""
+    N, Cin, Cout, S = case
+    L = _lib.load()
+    z = rnd(N, Cin, S, seed=20)
+    w = rnd(Cout, Cin, seed=21) / Cin ** 0.5
+    sc, sh = rnd(Cin, seed=22).abs() + 0.5, rnd(Cin, seed=23, scale=0.3)
+    a = torch.relu(z * sc.view(1, -1, 1) + sh.view(1, -1, 1))
+    ref = torch.einsum("oc,ncs->nos", w, a)
+    y = torch.full(ref.shape, float("nan"), device=DEV)
+    NP = L.msl_pwconv_fwd_num_partials(N, Cin, Cout, S)
+    part = torch.full((2 * Cout * NP,), float("nan"), dtype=torch.float64, device=DEV)
+    _lib.call("msl_pwconv_fwd", ptr(K(z)), ptr(K(sc)), ptr(K(sh)), ptr(K(w)), ptr(y), ptr(part), N, Cin, Cout, S, st())
+    close(y, ref, 1e-5, 1e-5, "pw fwd")
+    s, q = stats_from_partials(part, Cout, NP)
+    close(s, ref.double().sum((0, 2)), 1e-5, 1e-3, "pw sum")
+    close(q, (ref.double() ** 2).sum((0, 2)), 1e-5, 1e-3, "pw sumsq")
+    dy = rnd(*ref.shape, seed=24)
+    g = torch.full(z.shape, float("nan"), device=DEV)
+    _lib.call("msl_pwconv_bwd_data", ptr(K(dy)), ptr(K(w)), ptr(g), N, Cin, Cout, S, st())
+    close(g, torch.einsum("oc,nos->ncs", w, dy), 1e-5, 1e-5, "pw bwd data")
+
+
+@pytest.mark.parametrize("case", _rng_shapes(202, 8, lambda r: (r.choice([1, 1, 2, 3]),
+                                                                (r.randint(3, 20), r.randint(3, 24), r.randint(3, 150)),
+                                                                r.choice([(2, 2, 2), (1, 2, 2)]))),
+                         ids=lambda c: "cin%d_%dx%dx%d_s%d" % (c[0], *c[1], c[2][0]))
+def test_stem_fwd_random_shapes(case):
+    """MFMA stem forward at seeded random volumes: odd sizes, rows shorter and longer than one 64-column chunk, idle
+    waves (fewer chunks than wave slots), both stride patterns."""
+    cin, dims, stride = case
+    L = _lib.load()
+    N = 2
+    x, w = rnd(N, cin, *dims, seed=30), rnd(32, cin, 3, 3, 3, seed=31, scale=0.3)
+    ref = F.conv3d(x, w, stride=stride, padding=1)
+    y = torch.full(ref.shape, float("nan"), device=DEV)
+    od, oh, ow = ref.shape[2:]
+    NP = L.msl_stem_conv_fwd_num_partials(N, od, oh, ow)
+    part = torch.full((2 * 32 * NP,), float("nan"), dtype=torch.float64, device=DEV)
+    _lib.call("msl_stem_conv_fwd", ptr(K(x)), ptr(K(w)), ptr(y), ptr(part), N, cin, *dims, *stride, st())
+    close(y, ref, 1e-5, 1e-5, "stem fwd")
+    s, q = stats_from_partials(part, 32, NP)
+    close(s, ref.double().sum((0, 2, 3, 4)), 1e-5, 1e-3, "stem sum")
+    close(q, (ref.double() ** 2).sum((0, 2, 3, 4)), 1e-5, 1e-3, "stem sumsq")
+
+
+@pytest.mark.parametrize("case", _rng_shapes(303, 6, lambda r: (r.choice([1, 1, 2]),
+                                                                (2 * r.randint(2, 10), 2 * r.randint(2, 10), 8 * r.randint(1, 20)))),
+                         ids=lambda c: "cin%d_%dx%dx%d" % (c[0], *c[1]))
+def test_fused_stem_backward_random_shapes(case):
+    """Both halves of the stem backward that never stores dL/d(stem activation), at seeded random even volumes (the fused
+    pass needs the stem's output rows to be a multiple of 4 wide; other shapes take the materialising path)."""
+    _fused_stem_case(*case)
