@@ -58,6 +58,11 @@ int msl_bn_bwd_finalize_coef(const double* partials, int num_partials, double co
 int msl_bn_relu_bwd_apply(const float* g, const float* y, const float* scale, const float* shift,
                           const float* mean, const float* invstd, const float* c1, const float* c2, float* dy,
                           int N, int C, int S, void* stream);
+/* msl_bn_bwd_finalize + msl_bn_relu_bwd_apply in one launch (for <= 256 partials per channel): bn_vec = the (>= 6, C)
+ * block [scale, shift, mean, invstd, c1, c2, ...], rows 4-5 are written */
+int msl_bn_relu_bwd_finalize_apply(const double* partials, int num_partials, double count, const float* g, const float* y,
+                                   float* bn_vec, float* dgamma, float* dbeta, float* dy, int N, int C, int S,
+                                   void* stream);
 
 /* the three steps above in one launch (one workgroup per channel); for N*S <= 65536 elements per channel */
 int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, const float* shift, const float* mean,

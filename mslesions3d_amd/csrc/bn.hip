@@ -227,9 +227,42 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const double* __res
 __global__ __launch_bounds__(256) void bn_relu_bwd_apply_kernel(
     const float* __restrict__ g, const float* __restrict__ y, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, const float* __restrict__ invstd,
-    const float* __restrict__ c1, const float* __restrict__ c2, float* __restrict__ dy, int C, int S) {
+    const float* __restrict__ c1, const float* __restrict__ c2, float* __restrict__ dy, int C, int S,
+    const double* __restrict__ partials, int NP, double count, float* __restrict__ dgamma, float* __restrict__ dbeta,
+    float* __restrict__ c1_out, float* __restrict__ c2_out) {
   const int c = blockIdx.y, n = blockIdx.z;
-  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c], k1 = c1[c], k2 = c2[c];
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+  float k1, k2;
+  if (partials) {
+    // finalize folded in (NP is small here): every workgroup of the channel sums the same partials in the same order
+    // (wave 0, lanes strided, DPP tree), one of them publishes dgamma / dbeta / c1 / c2 - no separate launch on the chain
+    __shared__ float kk[2];
+    if (threadIdx.x < 64) {
+      double s = 0.0, q = 0.0;
+      for (int p = threadIdx.x; p < NP; p += 64) {
+        s += partials[(size_t)c * NP + p];
+        q += partials[((size_t)C + c) * NP + p];
+      }
+      s = msl::wave_sum(s);
+      q = msl::wave_sum(q);
+      if (threadIdx.x == 0) {
+        kk[0] = (float)(s / count);
+        kk[1] = (float)(q / count);
+        if (blockIdx.x == 0 && n == 0) {
+          dbeta[c] = (float)s;
+          dgamma[c] = (float)q;
+          c1_out[c] = kk[0];
+          c2_out[c] = kk[1];
+        }
+      }
+    }
+    __syncthreads();
+    k1 = kk[0];
+    k2 = kk[1];
+  } else {
+    k1 = c1[c];
+    k2 = c2[c];
+  }
   const size_t base = ((size_t)n * C + c) * S;
   if ((S & 3) == 0) {
     for (int i = (blockIdx.x * 256 + threadIdx.x) * 4; i < S; i += gridDim.x * 256 * 4) {
@@ -534,7 +567,22 @@ int msl_bn_relu_bwd_apply(const float* g, const float* y, const float* scale, co
   if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
   const int gx = min(msl::cdiv(S, 1024), 64);
   hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, g, y, scale,
-                     shift, mean, invstd, c1, c2, dy, C, S);
+                     shift, mean, invstd, c1, c2, dy, C, S, (const double*)nullptr, 0, 1.0, (float*)nullptr,
+                     (float*)nullptr, (float*)nullptr, (float*)nullptr);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// msl_bn_bwd_finalize + msl_bn_relu_bwd_apply in one launch, for reduce partials that are few (<= 256 per channel):
+// bn_vec is the (>= 6, C) vector block [scale, shift, mean, invstd, c1, c2, ...]; rows 4, 5 are written.
+int msl_bn_relu_bwd_finalize_apply(const double* partials, int num_partials, double count, const float* g, const float* y,
+                                   float* bn_vec, float* dgamma, float* dbeta, float* dy, int N, int C, int S,
+                                   void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0 || num_partials <= 0 || !partials || !bn_vec) return MSL_ERR_ARG;
+  const int gx = min(msl::cdiv(S, 1024), 64);
+  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, g, y, bn_vec,
+                     bn_vec + C, bn_vec + 2 * C, bn_vec + 3 * C, (const float*)nullptr, (const float*)nullptr, dy, C, S,
+                     partials, num_partials, count, dgamma, dbeta, bn_vec + 4 * C, bn_vec + 5 * C);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

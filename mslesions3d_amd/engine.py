@@ -485,6 +485,10 @@ class Engine:
             _lib.call("msl_bn_bwd_finalize_coef", ptr(pl.partials), pre_np, float(count), ptr(gv[bn_name + ".weight"]),
                       ptr(gv[bn_name + ".bias"]), ptr(vec), C, st)
             return
+        if pre_np is not None and apply and pre_np <= 256:
+            self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_finalize_apply", ptr(pl.partials), pre_np, float(count), ptr(g),
+                    ptr(y), ptr(vec), ptr(gv[bn_name + ".weight"]), ptr(gv[bn_name + ".bias"]), ptr(g), N, C, S, st)
+            return
         if pre_np is not None:
             _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), pre_np, float(count), ptr(gv[bn_name + ".weight"]),
                       ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
@@ -499,6 +503,10 @@ class Engine:
         NP = L.msl_bn_relu_bwd_num_partials(N, S)
         self._k("bn_bwd_reduce:" + bn_name, "msl_bn_relu_bwd_reduce", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(pl.partials), N, C, S, st)
+        if NP <= 256:
+            self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_finalize_apply", ptr(pl.partials), NP, float(count), ptr(g),
+                    ptr(y), ptr(vec), ptr(gv[bn_name + ".weight"]), ptr(gv[bn_name + ".bias"]), ptr(g), N, C, S, st)
+            return
         _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(count), ptr(gv[bn_name + ".weight"]),
                   ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
         self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
