@@ -460,8 +460,17 @@ __global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
 __global__ __launch_bounds__(64) void dw_bwd_weight_finalize_kernel(const double* __restrict__ partials, int NP,
                                                                     float* __restrict__ dw, int count) {
   const int i = blockIdx.x, lane = threadIdx.x;
+  const double* ps = partials + (size_t)i * NP;
   double s = 0.0;
-  for (int p = lane; p < NP; p += 64) s += partials[(size_t)i * NP + p];
+  int p = lane;
+  for (; p + 7 * 64 < NP; p += 8 * 64) {  // 8 independent loads in flight; additions in index order
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = ps[p + u * 64];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; p < NP; p += 64) s += ps[p];
   s = msl::wave_sum(s);
   if (lane == 0) dw[i] = (float)s;
 }

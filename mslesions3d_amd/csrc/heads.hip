@@ -159,8 +159,17 @@ __global__ __launch_bounds__(256) void head_fwd_finalize_kernel(const float* __r
   if (i >= N * S * quads) return;
   const int qd = i % quads, P = (i / quads) % S, n = i / (quads * S);
   f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < KSG; ++k)
-    s += *reinterpret_cast<const f32x4*>(slabs + (((size_t)k * N + n) * S + P) * (16 * MT) + qd * 4);
+  const float* p = slabs + ((size_t)n * S + P) * (16 * MT) + qd * 4;
+  const size_t kstride = (size_t)N * S * (16 * MT);
+  int k = 0;
+  for (; k + 8 <= KSG; k += 8) {  // 8 independent loads in flight; the additions keep the order k = 0, 1, 2, ...
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(k + u) * kstride);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < KSG; ++k) s += *reinterpret_cast<const f32x4*>(p + (size_t)k * kstride);
   write_head_outputs(s, qd / 4, qd % 4, n, P, S, loc_b, cl_b, locs, scores, Ptot, prior_off, ncls, co_total);
 }
 
@@ -324,8 +333,17 @@ __global__ __launch_bounds__(256) void head_bwd_weight_reduce_kernel(const float
   const int ct = ci / 16, cil = ci % 16, mt = co / 16, col = co % 16;
   const int CT = C / 16;
   float s = 0.f;
-  for (int k = 0; k < nslabs; ++k)
-    s += slabs[((size_t)k * CT + ct) * (27 * MT * 256) + (size_t)(tap * MT + mt) * 256 + col * 16 + cil];
+  const float* p = slabs + (size_t)ct * (27 * MT * 256) + (size_t)(tap * MT + mt) * 256 + col * 16 + cil;
+  const size_t kstride = (size_t)CT * (27 * MT * 256);
+  int k = 0;
+  for (; k + 8 <= nslabs; k += 8) {  // 8 independent loads in flight; additions in slab order
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + u) * kstride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; k < nslabs; ++k) s += p[(size_t)k * kstride];
   if (co < 12) dloc_w[((size_t)co * C + ci) * 27 + tap] = s;
   else dcl_w[((size_t)(co - 12) * C + ci) * 27 + tap] = s;
 }
@@ -340,7 +358,15 @@ __global__ __launch_bounds__(256) void head_bias_grad_kernel(const float* __rest
   for (int n = 0; n < N; ++n) {
     const float* p = dO_pad + ((size_t)n * CO + co) * volp;
     float part = 0.f;
-    for (size_t i = threadIdx.x; i < volp; i += 256) part += p[i];
+    size_t i = threadIdx.x;
+    for (; i + 7 * 256 < volp; i += 8 * 256) {  // 8 independent loads in flight; additions in index order
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[i + (size_t)u * 256];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) part += v[u];
+    }
+    for (; i < volp; i += 256) part += p[i];
     s += (double)part;
   }
   const double t = msl::block_sum(s, scratch);
