@@ -636,7 +636,8 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
   const int RS = stride == 1 ? W + 8 : ((OW + 3) & ~3) + ((OW + 4) & ~3);
   const int PS = (H + 2) * RS;
   const int OWV = OW / 4, Lp = OH * OWV;
-  if (H * W > 1024) {  // stream
+  static const int stream_min_hw = getenv("MSL_DW_STREAM_MIN_HW") ? atoi(getenv("MSL_DW_STREAM_MIN_HW")) : 1025;
+  if (H * W >= stream_min_hw) {  // stream
     int G = 1;
     int ipt = msl::cdiv(G * Lp, 256);
     int lpt = msl::cdiv(G * H * (W / 4), 256);
