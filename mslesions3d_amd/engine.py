@@ -182,7 +182,8 @@ class Plan:
                 D, H, W = self.dims[i]
                 ws = max(ws, L.msl_pwconv_bwd_weight_workspace_bytes(N, specs[i]["cin"], specs[i]["cout"], D * H * W))
             self.ws = torch.empty(max(ws // 4, 1), **f32)
-            # private scratch of the weight-gradient stream (its kernels overlap the main stream's)
+            # private scratch of the weight-gradient launches (they overlap the main stream's kernels, and pl.partials may
+            # hold BatchNorm reduce partials that are consumed only after the weight gradients of the layer were enqueued)
             self.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
             self.partials_w = torch.empty_like(self.partials)
             # fused stem backward (block 1 is a stride-2 depthwise layer fed by a 32-channel stem that is not a head
@@ -645,7 +646,7 @@ class Engine:
                             ptr(gv[name + ".conv1.weight"]), sp["cin"], stW)
                     return
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
-                        ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w if ms else pl.partials),
+                        ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w),  # never pl.partials: it may hold the next BatchNorm's reduce partials
                         N, sp["cin"], pd, ph, pw, s, stW)
 
             # issue what the previous layer left for the side streams, then queue this layer's

@@ -288,6 +288,32 @@ def test_fused_stem_backward_matches_the_materialised_path():
     assert "base.features.2.conv1.weight" in same and "pred_convs.loc_convs.0.weight" in same
 
 
+def test_engine_schedule_options_agree():
+    """Single-stream vs three-stream schedule x fused vs materialising stem backward x BatchNorm fold threshold x
+    recorded vs Python-driven launches: two optimisation steps end at the same parameters (fp32 reduction-order noise only).
+    48 x 64 x 64 x 2 channels is the smallest golden shape on which the big-layer BatchNorm paths (reduce partials emitted by the
+    depthwise backward) are taken."""
+    import itertools
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n, cin = (48, 64, 64), 2, 2
+    x = detinit.make_volume_batch(5, n, cin, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, n, size)
+    boxes, labels = [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels]
+    ref = None
+    for ms, fuse, fold, progs in itertools.product((True, False), (True, False), (0, 32), (True, False)):
+        m = hip_model(cin, size, lr=1e-3, batch_size=n).train()
+        m._engine.multi_stream, m._engine.fuse_stem, m._engine.fold_np_max = ms, fuse, fold
+        tr = FusedTrainer(m)
+        tr.use_programs = progs
+        losses = [tr.step(x, boxes, labels)["loss"] for _ in range(2)]
+        p = torch.cat([q.detach().reshape(-1) for q in m.parameters()]).double().cpu()
+        if ref is None:
+            ref = (losses, p)
+        what = f"multi_stream={ms} fuse_stem={fuse} fold_np_max={fold} programs={progs}"
+        assert max(abs(a - b) / abs(b) for a, b in zip(losses, ref[0])) < 1e-5, what
+        assert float((p - ref[1]).abs().max() / ref[1].abs().max()) < 1e-4, what
+
+
 def test_determinism_run_to_run():
     size, n = (64, 64, 64), 2
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
