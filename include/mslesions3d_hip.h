@@ -191,13 +191,16 @@ int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long
 /* ---- LSSD3D.detect_objects (ssd3d.py:344-460): softmax, decode, filter, sort, 3D NMS, top-k ---------------
  * cap = 10*top_k (<= 4096), Wn = ceil(cap/64), K1 = ncls-1.  Caller-allocated scratch:
  *   probs (N,K1,P) f32; boxes (N,P,6) f32; sorted_idx (N,K1,cap) i32; ncand (N*K1) i32;
- *   mask (N,K1,cap,Wn) u64; keep_bits (N,K1,Wn) u64; nkept (N*K1) i32; tmp_scores (N,K1*cap) f32; tmp_ref same i32
+ *   mask (N,K1,cap,Wn) u64; keep_bits (N,K1,Wn) u64; nkept (N*K1) i32; tmp_scores (N,K1*cap) f32; tmp_ref same i32;
+ *   select_ws: msl_detect_select_ws_ints(N,P,ncls) i32 (score histogram + shortlist of the candidates that can reach the
+ *   best cap: the stable order is then found among ~cap candidates instead of all P)
  * Outputs: out_boxes (N,top_k,6), out_scores (N,top_k), out_labels / out_prior (N,top_k) i64, out_count (N) i32. */
+size_t msl_detect_select_ws_ints(int N, int P, int ncls);
 int msl_detect_objects(const float* locs, const float* scores, const float* priors_c, int N, int P, int ncls,
                        float min_score, float max_overlap, int top_k, float* probs, float* boxes, int* sorted_idx,
                        int* ncand, unsigned long long* mask, unsigned long long* keep_bits, int* nkept,
-                       float* tmp_scores, int* tmp_ref, float* out_boxes, float* out_scores, long long* out_labels,
-                       long long* out_prior, int* out_count, void* stream);
+                       float* tmp_scores, int* tmp_ref, int* select_ws, float* out_boxes, float* out_scores,
+                       long long* out_labels, long long* out_prior, int* out_count, void* stream);
 
 /* ---- optimiser + NaN guard : ssd3d.py:704-722, :258-261 ---------------------------------------------------- */
 /* hp (device, 8 floats): step_size(bias), step_size(other), sqrt(bias_correction2), beta1, beta2, eps,

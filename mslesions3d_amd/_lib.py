@@ -71,7 +71,8 @@ _SIGNATURES = {
     "msl_multibox_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_multibox_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_multibox_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
-    "msl_detect_objects": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I] + [_P] * 14 + [_P]),
+    "msl_detect_select_ws_ints": (_Z, [_I, _I, _I]),
+    "msl_detect_objects": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I] + [_P] * 15 + [_P]),
     "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "msl_nan_flag": (_I, [_P, _Z, _P, _I, _P]),
     "msl_program_fn_id": (_I, [_P]),
@@ -126,7 +127,7 @@ def new_event():
 
 
 # -- native replay ----------------------------------------------------------------------------------------------
-_SLOT_STRIDE = 24
+_SLOT_STRIDE = 28
 _fn_ids = {}
 
 

@@ -383,6 +383,7 @@ class LSSD3D(nn.Module):
                       nkept=torch.zeros(N * k1, dtype=i32, device=dev),
                       tmp_s=torch.empty((N, k1 * cap), dtype=f32, device=dev),
                       tmp_r=torch.empty((N, k1 * cap), dtype=i32, device=dev),
+                      sel=torch.zeros(int(_lib.load().msl_detect_select_ws_ints(N, P, ncls)), dtype=i32, device=dev),
                       ob=torch.empty((N, top_k, 6), dtype=f32, device=dev),
                       os=torch.empty((N, top_k), dtype=f32, device=dev),
                       ol=torch.empty((N, top_k), dtype=i64, device=dev),
@@ -411,7 +412,7 @@ class LSSD3D(nn.Module):
         N, P, ncls = locs.size(0), locs.size(1), scores.size(2)
         _lib.call("msl_detect_objects", ptr(locs), ptr(scores), ptr(self.priors_cxcycz), N, P, ncls, float(min_score),
                   float(max_overlap), int(top_k), ptr(w["probs"]), ptr(w["boxes"]), ptr(w["sorted_idx"]), ptr(w["ncand"]),
-                  ptr(w["mask"]), ptr(w["keep"]), ptr(w["nkept"]), ptr(w["tmp_s"]), ptr(w["tmp_r"]), ptr(w["ob"]),
+                  ptr(w["mask"]), ptr(w["keep"]), ptr(w["nkept"]), ptr(w["tmp_s"]), ptr(w["tmp_r"]), ptr(w["sel"]), ptr(w["ob"]),
                   ptr(w["os"]), ptr(w["ol"]), ptr(w["op"]), ptr(w["oc"]), _stream())
 
     @staticmethod

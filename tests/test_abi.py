@@ -76,9 +76,9 @@ def test_native_program_runner_covers_the_abi():
     # host-only call through the runner: msl_abi_version() == 1 means rc 1 is reported as the failing code
     import ctypes
     ids = (ctypes.c_int * 1)(lib.msl_program_fn_id(b"msl_abi_version"))
-    slots = (ctypes.c_ulonglong * 24)()
+    slots = (ctypes.c_ulonglong * 28)()
     failed = ctypes.c_int(-1)
-    assert lib.msl_run_program(ids, slots, 24, 1, ctypes.byref(failed)) == 1 and failed.value == 0
+    assert lib.msl_run_program(ids, slots, 28, 1, ctypes.byref(failed)) == 1 and failed.value == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch):

@@ -1,5 +1,6 @@
 """Inference path of BASELINE configs[3] (192^3, batch 2) in fp32: eval forward + decode + 3-D NMS (predict_step),
-checked against the CPU oracle on the same volumes (keep-lists bit-exact, boxes within 1e-4) and timed.
+timed, then checked against the CPU oracle on the same volumes (keep-lists bit-exact, boxes within 1e-4; the check runs
+last: the oracle's CPU worker threads would otherwise compete with the timed host loop).
 Usage (GPU box): python tools/bench_infer.py [--size 192] [--batch 2] [--no-oracle]"""
 import argparse
 import os
@@ -38,6 +39,19 @@ with torch.no_grad():
 torch.cuda.synchronize()
 print(f"{args.size}^3 batch {args.batch}: priors {locs.shape[1]}, detections per volume {[len(b) for b in det[0]]}")
 
+for _ in range(3):
+    model.predict_step({"img": x})
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+nb = 0
+for _ in range(args.steps):
+    out = model.predict_step({"img": x})
+    nb += sum(len(b) for b in out[0])
+torch.cuda.synchronize()
+dt = time.perf_counter() - t0
+print(f"predict_step: {dt / args.steps * 1e3:.2f} ms per batch of {args.batch} -> {args.batch * args.steps / dt:.0f} volumes/s, "
+      f"{nb / dt:.0f} boxes/s (fp32, host sync per batch for the detection counts)")
+
 if not args.no_oracle:
     from oracle import detect as odet  # noqa: E402  (checker only)
     from oracle.network import OracleSSD3D  # noqa: E402
@@ -55,16 +69,3 @@ if not args.no_oracle:
         err = (det[0][i].cpu() - torch.as_tensor(ob[i])).abs().max().item() if len(ob[i]) else 0.0
         assert err <= 1e-4, err
     print("parity: NMS keep-lists bit-exact, boxes within 1e-4")
-
-for _ in range(3):
-    model.predict_step({"img": x})
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-nb = 0
-for _ in range(args.steps):
-    out = model.predict_step({"img": x})
-    nb += sum(len(b) for b in out[0])
-torch.cuda.synchronize()
-dt = time.perf_counter() - t0
-print(f"predict_step: {dt / args.steps * 1e3:.2f} ms per batch of {args.batch} -> {args.batch * args.steps / dt:.0f} volumes/s, "
-      f"{nb / dt:.0f} boxes/s (fp32, host sync per batch for the detection counts)")
