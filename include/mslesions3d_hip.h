@@ -36,6 +36,8 @@ int msl_bn_finalize_table_set(void* host_table, int index, int first_block, cons
                               float* scale, float* shift, float* save_mean, float* save_invstd, int C);
 int msl_bn_finalize_batch(const void* device_table, int n_entries, int total_channels, void* stream);
 /* eval mode: scale/shift from the running statistics */
+/* eval-mode (scale, shift) of every BatchNorm in a table built with msl_bn_finalize_table_set, one launch */
+int msl_bn_eval_affine_batch(const void* device_table, int n_entries, int total_channels, void* stream);
 int msl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
                        float eps, float* scale, float* shift, int C, void* stream);
 /* relu(y*scale+shift) into a plain (N,C,D,H,W) tensor and/or a zero-haloed (N,C,D+2,H+2,W+2) one (either may be NULL) */

@@ -18,6 +18,7 @@ _SIGNATURES = {
     "msl_bn_finalize_entry_bytes": (_Z, []),
     "msl_bn_finalize_table_set": (_I, [_P, _I, _I, _P, _I, _D, _P, _P, _P, _P, _P, _F, _F, _P, _P, _P, _P, _I]),
     "msl_bn_finalize_batch": (_I, [_P, _I, _I, _P]),
+    "msl_bn_eval_affine_batch": (_I, [_P, _I, _I, _P]),
     "msl_bn_eval_affine": (_I, [_P, _P, _P, _P, _F, _P, _P, _I, _P]),
     "msl_bn_relu_materialize": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msl_bn_relu_materialize_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _I, _I, _I, _I, _I, _P]),

@@ -91,6 +91,22 @@ __global__ void bn_eval_affine_kernel(const float* __restrict__ gamma, const flo
   shift[c] = beta[c] - running_mean[c] * sc;
 }
 
+// every BatchNorm of the network in one launch (table as for bn_finalize_batch_kernel; one thread per channel): the
+// arithmetic of bn_eval_affine_kernel, bit for bit
+__global__ __launch_bounds__(128) void bn_eval_affine_batch_kernel(const BnFinalizeEntry* __restrict__ table, int n_entries,
+                                                                   int total_channels) {
+  const int i = blockIdx.x * 128 + threadIdx.x;
+  if (i >= total_channels) return;
+  int e = 0;
+  while (e + 1 < n_entries && i >= table[e + 1].first_block) ++e;
+  const BnFinalizeEntry& t = table[e];
+  const int c = i - t.first_block;
+  const float invstd = 1.0f / sqrtf(t.running_var[c] + t.fold.eps);
+  const float sc = t.fold.gamma[c] * invstd;
+  t.scale[c] = sc;
+  t.shift[c] = t.fold.beta[c] - t.running_mean[c] * sc;
+}
+
 // out = relu(y*scale+shift), written in plain NCDHW and/or in a zero-haloed layout
 // (N,C,D+2,H+2,W+2) that lets the head convolutions run without bounds checks.
 __global__ __launch_bounds__(256) void bn_relu_materialize_kernel(
@@ -462,6 +478,15 @@ int msl_bn_finalize_batch(const void* device_table, int n_entries, int total_cha
   if (!device_table || n_entries <= 0 || total_channels <= 0) return MSL_ERR_ARG;
   hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(total_channels), dim3(64), 0, (hipStream_t)stream,
                      reinterpret_cast<const BnFinalizeEntry*>(device_table), n_entries);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// eval-mode (scale, shift) of every BatchNorm listed in the table (msl_bn_finalize_table_set) in ONE launch
+int msl_bn_eval_affine_batch(const void* device_table, int n_entries, int total_channels, void* stream) {
+  if (!device_table || n_entries <= 0 || total_channels <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_eval_affine_batch_kernel, dim3(msl::cdiv(total_channels, 128)), dim3(128), 0, (hipStream_t)stream,
+                     reinterpret_cast<const BnFinalizeEntry*>(device_table), n_entries, total_channels);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -368,6 +368,14 @@ class Engine:
                 fn()
             deferred = []
 
+        if not training:
+            # eval mode: (scale, shift) of all BatchNorms depend on parameters and running statistics only - one launch
+            every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], 1.0)]
+            for i in range(1, len(specs)):
+                every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], 1.0),
+                          (feats[i].bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], 1.0)]
+            self._finalize_all(pl, every, st, eval_mode=True)
+
         # stem (features[0] = Conv3d + BN + ReLU)
         D, H, W = pl.in_dims
         sd, sh, sw = specs[0]["stride"]
@@ -375,6 +383,8 @@ class Engine:
                 ptr(pl.part_y[0]) if training else None, N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         od, oh, ow = pl.dims[0]
         def bn_done(bn, vec, part, NP, count, name):
+            if not training:
+                return  # done above, for all layers at once
             if folds(NP):
                 finalize_later(bn, vec, part, NP, count, name)
             else:
@@ -442,11 +452,22 @@ class Engine:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores
 
-    def _finalize_all(self, pl, bn_layers, st):
-        """One launch for the running statistics and backward vectors of every BatchNorm (table built once per plan)."""
+    def _finalize_all(self, pl, bn_layers, st, eval_mode=False):
+        """One launch for the running statistics and backward vectors of the listed BatchNorms (table built once per
+        plan and mode); ``eval_mode``: one launch for their eval-mode (scale, shift) instead."""
         import ctypes
         L = _lib.load()
-        key = tuple((ptr(bn.weight), ptr(bn.running_mean)) for bn, *_ in bn_layers)
+        key = (eval_mode,) + tuple((ptr(bn.weight), ptr(bn.running_mean)) for bn, *_ in bn_layers)
+        if eval_mode:
+            if getattr(pl, "bn_eval_table_key", None) != key:
+                keep = (getattr(pl, "bn_table", None), getattr(pl, "bn_table_key", None), getattr(pl, "bn_table_n", None),
+                        getattr(pl, "bn_table_channels", None))
+                pl.bn_table_key = None
+                self._finalize_all(pl, bn_layers, None)  # builds pl.bn_table for this list (no launch: st is None)
+                pl.bn_eval_table, pl.bn_eval_n, pl.bn_eval_channels, pl.bn_eval_table_key = pl.bn_table, pl.bn_table_n, pl.bn_table_channels, key
+                pl.bn_table, pl.bn_table_key, pl.bn_table_n, pl.bn_table_channels = keep
+            _lib.call("msl_bn_eval_affine_batch", ptr(pl.bn_eval_table), pl.bn_eval_n, pl.bn_eval_channels, st, tag="bn_eval_all")
+            return
         if getattr(pl, "bn_table_key", None) != key:
             esz = L.msl_bn_finalize_entry_bytes()
             host = (ctypes.c_ubyte * (esz * len(bn_layers)))()
@@ -462,6 +483,8 @@ class Engine:
                 first += C
             pl.bn_table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(vec.device)
             pl.bn_table_key, pl.bn_table_n, pl.bn_table_channels = key, len(bn_layers), first
+        if st is None:
+            return
         _lib.call("msl_bn_finalize_batch", ptr(pl.bn_table), pl.bn_table_n, pl.bn_table_channels, st, tag="bn_finalize_all")
 
     def _head_forward(self, pl, f, st):
