@@ -490,3 +490,23 @@ def test_train_and_predict_entry_points(tmp_path):
     from mslesions3d_amd.ssd3d import LSSD3D
     re = LSSD3D.load_from_checkpoint(ckpts[-1])
     assert list(re.state_dict().keys()) == list(model.state_dict().keys())
+
+
+def test_data_parallel_two_ranks_share_one_gpu():
+    """The N > 1 path of bench.py (one process per rank, gradient buckets all-reduced beside the backward pass, launch
+    programs with the reducer's hooks, replicas checked for identical parameters at the end) with two ranks on this one GPU.
+    Backend gloo here (RCCL refuses two ranks on one device); the driver's scaling run uses RCCL, one rank per GPU."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--size", "64",
+           "--batch", "2", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
