@@ -330,28 +330,30 @@ __global__ __launch_bounds__(NW * 64) void pw_gemm_ksplit_kernel(const float* __
 //                                meet in LDS and every wave finishes 32/NWK rows (sum order j = 0..NWK-1, fixed).
 constexpr int WV_LD = 33;
 
-template <int KW, int MT, bool AFFINE, bool STATS, bool TRANS_W, int NWK>
+template <int KW, int MT, bool AFFINE, bool STATS, bool TRANS_W, int NWK, int NT = 1>
 __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
     const float* __restrict__ X, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ Wt, float* __restrict__ Y, double* __restrict__ partials, int M, int K, int S,
     msl::BnFold fold) {
   constexpr int KH = KW / 2;
-  static_assert(NWK == 1 || MT == 1, "the K-split form owns one row tile");
+  static_assert(NWK == 1 || (MT == 1 && NT == 1), "the K-split form owns one tile");
   __shared__ float red[NWK == 1 ? 2 * 4 * MT * 32 : NWK * 32 * WV_LD];
   __shared__ float f_sc[AFFINE ? FOLD_MAXK : 1], f_sh[AFFINE ? FOLD_MAXK : 1];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
   const int n = blockIdx.z;
   const int m0 = blockIdx.y * 32 * MT;
-  const int ctile = NWK == 1 ? blockIdx.x * 4 + wv : blockIdx.x;
+  const int ctile = NWK == 1 ? (blockIdx.x * 4 + wv) * NT : blockIdx.x;  // NT neighbouring column tiles per wave
   const int kb = (NWK == 1 ? 0 : wv * KW) + h * KH;  // this lane's first input channel
-  const int col = ctile * 32 + c;
-  const bool cin = col < S;
-
-  float xr[KH], wr[MT][KH];
-  {
-    const float* xp = X + ((size_t)n * K + kb) * S + (cin ? col : S - 1);
+  int col[NT];
+  bool cin[NT];
+  float xr[NT][KH], wr[MT][KH];
 #pragma unroll
-    for (int kk = 0; kk < KH; ++kk) xr[kk] = xp[(size_t)kk * S];
+  for (int nt = 0; nt < NT; ++nt) {
+    col[nt] = (ctile + nt) * 32 + c;
+    cin[nt] = col[nt] < S;
+    const float* xp = X + ((size_t)n * K + kb) * S + (cin[nt] ? col[nt] : S - 1);
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) xr[nt][kk] = xp[(size_t)kk * S];
   }
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
@@ -375,7 +377,9 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
     if (fold.partials) {  // optional in-kernel BatchNorm fold (Engine.fold_bn): same (scale, shift) bits as the vectors
       msl::bn_fold_block(fold, 0, K, f_sc, f_sh);
 #pragma unroll
-      for (int kk = 0; kk < KH; ++kk) xr[kk] = cin ? msl::act(xr[kk], f_sc[kb + kk], f_sh[kb + kk]) : 0.f;
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) xr[nt][kk] = cin[nt] ? msl::act(xr[nt][kk], f_sc[kb + kk], f_sh[kb + kk]) : 0.f;
     } else {
       float sc[KH], sh[KH];
       const float4* sp = reinterpret_cast<const float4*>(in_scale + kb);
@@ -387,20 +391,29 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
         sh[4 * j] = b.x; sh[4 * j + 1] = b.y; sh[4 * j + 2] = b.z; sh[4 * j + 3] = b.w;
       }
 #pragma unroll
-      for (int kk = 0; kk < KH; ++kk) xr[kk] = cin ? msl::act(xr[kk], sc[kk], sh[kk]) : 0.f;
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) xr[nt][kk] = cin[nt] ? msl::act(xr[nt][kk], sc[kk], sh[kk]) : 0.f;
     }
   } else {
 #pragma unroll
-    for (int kk = 0; kk < KH; ++kk) xr[kk] = cin ? xr[kk] : 0.f;
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int kk = 0; kk < KH; ++kk) xr[nt][kk] = cin[nt] ? xr[nt][kk] : 0.f;
   }
 
-  f32x16 acc[MT];
+  f32x16 acc[MT][NT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x16){0};
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = (f32x16){0};
 #pragma unroll
   for (int kk = 0; kk < KH; ++kk)
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[mt][kk], xr[kk], acc[mt], 0, 0, 0);
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[mt][kk], xr[nt][kk], acc[mt][nt], 0, 0, 0);
 
   float* Yn = Y + (size_t)n * M * S;
   const int NP = gridDim.z * gridDim.x, p = n * gridDim.x + blockIdx.x;
@@ -411,10 +424,16 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-        const float v = acc[mt][r];
-        if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
+        float v = 0.f, v2 = 0.f;  // over this wave's NT column tiles
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float a = acc[mt][nt][r];
+          if (cin[nt]) Yn[(size_t)(m0 + row) * S + col[nt]] = a;
+          v += a;
+          v2 = fmaf(a, a, v2);
+        }
         if (STATS) {
-          const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);  // columns past S hold exact zeros
+          const float sm = msl::half32_sum(v), q = msl::half32_sum(v2);  // columns past S hold exact zeros
           if (c == msl::HALF32_SUM_LANE) {
             red[(wv * MT * 32 + row) * 2] = sm;
             red[(wv * MT * 32 + row) * 2 + 1] = q;
@@ -438,7 +457,7 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
   } else {
     float* mine = red + wv * 32 * WV_LD;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * WV_LD + c] = acc[0][r];
+    for (int r = 0; r < 16; ++r) mine[((r & 3) + 8 * (r >> 2) + 4 * h) * WV_LD + c] = acc[0][0][r];
     __syncthreads();
     constexpr int RPW = 32 / NWK;  // rows finished by each wave (NWK = 2, 4, 8)
 #pragma unroll
@@ -447,7 +466,7 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
       float v = 0.f;
 #pragma unroll
       for (int j = 0; j < NWK; ++j) v += red[(j * 32 + row) * WV_LD + c];
-      if (cin) Yn[(size_t)(m0 + row) * S + col] = v;
+      if (cin[0]) Yn[(size_t)(m0 + row) * S + col[0]] = v;
       if (STATS) {
         const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);
         if (c == msl::HALF32_SUM_LANE && partials) {
@@ -457,6 +476,17 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
       }
     }
   }
+}
+
+// column tiles per wave of the unsplit form (K <= 64): two when that still leaves >= 2 waves per SIMD - the weight rows, the
+// input affine and the statistics reduction are then paid once per 64 columns
+static inline int wave_nt(int N, int K, int M, int S) {
+  static const int force = getenv("MSL_PW_NT") ? atoi(getenv("MSL_PW_NT")) : 0;
+  if (K > 64) return 1;
+  if (force) return force;
+  const int mt = (M % 64 == 0) ? 2 : 1;
+  const long long waves = (long long)N * msl::cdiv(S, 32) * (M / (32 * mt));
+  return waves >= 4096 ? 2 : 1;
 }
 
 // which form runs a (K, M) GEMM: 0 = the LDS-staged kernels above, else KW (NWK = K / KW)
@@ -474,11 +504,20 @@ static int launch_wave(const float* X, const float* in_scale, const float* in_sh
   hipLaunchKernelGGL((pw_wave_kernel<KW_, MT_, AFFINE, STATS, TRANS_W, NWK_>),                                        \
                      dim3(msl::cdiv(S, NWK_ == 1 ? 128 : 32), M / (32 * MT_), N), dim3(NWK_ == 1 ? 256 : NWK_ * 64), \
                      0, st, X, in_scale, in_shift, Wt, Y, partials, M, K, S, fold)
+#define MSL_WV1(KW_, MT_)                                                                                              \
+  do {                                                                                                                 \
+    if (nt == 2)                                                                                                       \
+      hipLaunchKernelGGL((pw_wave_kernel<KW_, MT_, AFFINE, STATS, TRANS_W, 1, 2>), dim3(msl::cdiv(S, 256), M / (32 * MT_), N), \
+                         dim3(256), 0, st, X, in_scale, in_shift, Wt, Y, partials, M, K, S, fold);                     \
+    else                                                                                                               \
+      MSL_WV(KW_, MT_, 1);                                                                                             \
+  } while (0)
   const bool two = M % 64 == 0;
+  const int nt = STATS ? wave_nt(N, K, M, S) : 1;  // pays where the statistics epilogue is amortised (measured: tools/bench_pw.py)
   if (K == 32) {
-    if (two) MSL_WV(32, 2, 1); else MSL_WV(32, 1, 1);
+    if (two) MSL_WV1(32, 2); else MSL_WV1(32, 1);
   } else if (K == 64) {
-    if (two) MSL_WV(64, 2, 1); else MSL_WV(64, 1, 1);
+    if (two) MSL_WV1(64, 2); else MSL_WV1(64, 1);
   } else {
     switch (K / 64) {
       case 2: MSL_WV(64, 1, 2); break;
@@ -487,6 +526,7 @@ static int launch_wave(const float* X, const float* in_scale, const float* in_sh
       default: return MSL_ERR_UNSUPPORTED;
     }
   }
+#undef MSL_WV1
 #undef MSL_WV
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -648,7 +688,7 @@ static inline bool use_ksplit(int K, int M, int S, int N) {
 }
 
 int msl_pwconv_fwd_num_partials(int N, int Cin, int Cout, int S) {
-  if (wave_form(Cin, Cout)) return N * msl::cdiv(S, Cin <= 64 ? 128 : 32);
+  if (wave_form(Cin, Cout)) return N * msl::cdiv(S, Cin <= 64 ? 128 * wave_nt(N, Cin, Cout, S) : 32);
   return N * msl::cdiv(S, use_ksplit(Cin, Cout, S, N) ? KS_BN : BN);
 }
 
