@@ -339,6 +339,9 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     // re-read a live address) and dead slots are skipped with a scalar branch.  Along W lane l loads
     // dz[(ow >> 1) + (ow & 1)]; an odd voxel takes its kw = 2 tap (dz[ow >> 1]) from its even neighbour by DPP.
     const int OS1 = fs.OD1 * fs.OH1 * fs.OW1;
+    // workgroups b and b+8 run on the same XCD (one L2): give each XCD a contiguous range of chunks, so that the dz rows
+    // shared by neighbouring stem rows are fetched into one L2 instead of eight
+    const int lblock = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     struct Ctx {
       bool live, in, okl, odd;   // in/okl/odd: per lane
       bool vD[2], vH[2];         // wave-uniform from here on
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     const unsigned OS4 = (unsigned)OS * 4u, OS14 = (unsigned)OS1 * 4u;
     auto make_ctx = [&](int it) {
       Ctx c;
-      const int chunk = (blockIdx.x * iters + it) * 4 + wv;
+      const int chunk = (lblock * iters + it) * 4 + wv;
       c.live = it < iters && chunk < total_chunks;
       const int cc = c.live ? chunk : 0;
       const int seg = cc % chunks_per_row;
