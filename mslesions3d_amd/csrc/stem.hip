@@ -158,7 +158,10 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   };
   Tile cur;
   {
-    const int chunk0 = (blockIdx.x * 4 + wv) * iters;
+    // workgroups b and b+8 share an XCD (one L2): contiguous chunk ranges per XCD, so the input rows shared by
+    // neighbouring output rows are fetched into one L2
+    const int lblock = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+    const int chunk0 = (lblock * 4 + wv) * iters;
     cur.live = chunk0 < chunks_per_n;
     const int cc = cur.live ? chunk0 : 0;
     cur.seg = cc % chunks_per_row;
