@@ -326,7 +326,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
       const int ci = k / 27, t = k % 27;
       tapoff[nt] = (ci * 9 + t / 3) * SB_ROW_LD + (t % 3);
     } else {
-      tapoff[nt] = -1;
+      tapoff[nt] = 0;  // padding column of the GEMM: reads staged data, accumulates a value that the reduce kernel drops
     }
   }
   f32x16 acc[NT];
@@ -362,17 +362,39 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(
         (void*)msl::uniform_base(dy), 0, (int)((unsigned)N * 32u * (unsigned)OS1 * 4u), 0x00020000);
     const unsigned OS4 = (unsigned)OS * 4u, OS14 = (unsigned)OS1 * 4u;
+    // the wave walks `iters` CONSECUTIVE chunks: coordinates are decoded once and then advanced with scalar increments
+    // (four integer divisions per chunk otherwise), and consecutive rows share their dz rows in this CU's L1
+    int w_seg, w_oh, w_od, w_n;
+    {
+      const int chunk0 = (lblock * 4 + wv) * iters;
+      const int cc = chunk0 < total_chunks ? chunk0 : 0;
+      w_seg = cc % chunks_per_row;
+      int r = cc / chunks_per_row;
+      w_oh = r % OH;
+      r /= OH;
+      w_od = r % OD;
+      w_n = r / OD;
+    }
     auto make_ctx = [&](int it) {
       Ctx c;
-      const int chunk = (lblock * iters + it) * 4 + wv;
+      const int chunk = (lblock * 4 + wv) * iters + it;
       c.live = it < iters && chunk < total_chunks;
-      const int cc = c.live ? chunk : 0;
-      const int seg = cc % chunks_per_row;
-      int r = cc / chunks_per_row;
-      c.oh = r % OH;
-      r /= OH;
-      c.od = r % OD;
-      c.n = r / OD;
+      if (it > 0) {  // advance by one chunk
+        if (++w_seg == chunks_per_row) {
+          w_seg = 0;
+          if (++w_oh == OH) {
+            w_oh = 0;
+            if (++w_od == OD) {
+              w_od = 0;
+              ++w_n;
+            }
+          }
+        }
+      }
+      c.oh = c.live ? w_oh : 0;
+      c.od = c.live ? w_od : 0;
+      c.n = c.live ? w_n : 0;
+      const int seg = c.live ? w_seg : 0;
       c.ow0 = seg * 64;
       const int npos = c.live ? min(64, OW - c.ow0) : 0;
       c.in = lane < npos;
@@ -499,7 +521,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
         const float a = dyt[(lane & 31) * SB_DY_LD + pos];
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const float b = tapoff[nt] >= 0 ? rows[tapoff[nt] + pos * sw] : 0.f;
+          const float b = rows[tapoff[nt] + pos * sw];
           acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
         }
       }
@@ -590,7 +612,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
       const float a = dyt[(lane & 31) * SB_DY_LD + pos];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const float b = tapoff[nt] >= 0 ? rows[tapoff[nt] + pos * sw] : 0.f;
+        const float b = rows[tapoff[nt] + pos * sw];
         acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[nt], 0, 0, 0);
       }
     }
