@@ -500,10 +500,14 @@ def test_data_parallel_two_ranks_share_one_gpu():
     import os
     import subprocess
     import sys
+    import socket
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MSL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--size", "64",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--size", "64",
            "--batch", "2", "--no-cpu-baseline"]
     r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
