@@ -29,13 +29,13 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=4, help="volumes per GPU")
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=5)
+    ap.add_argument("--cpu-steps", type=int, default=25)  # ~10 s of CPU work
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch and print a table (stderr)")
     return ap.parse_args()
 
