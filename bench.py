@@ -128,6 +128,13 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     prof = eng.stop_profile()
+    # SURVEY 8(d)'s aggregate over ALL seven depthwise forwards, timed in situ in a short pass of its own (14 more
+    # event records per step would perturb the timed region above): outside the timed region, not part of `value`
+    dw_all = None
+    if not args.profile_all:
+        eng.start_profile({f"dw_fwd{i}" for i in range(1, 8)})
+        run(20)
+        dw_all = eng.stop_profile()
     # diagnostic: pure host cost of enqueueing one step (GPU idle, empty queues -> no back-pressure)
     t_enq = []
     for _ in range(5):
@@ -184,6 +191,17 @@ def main():
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": len(ms)},
         }
+        if dw_all and all(dw_all.get(f"dw_fwd{i}") for i in range(1, 8)):
+            # block i reads (N, C_i, dims[i-1]) and writes (N, C_i, dims[i]) once, plus its taps
+            chans = [32, 64, 128, 128, 256, 256, 512]
+            vol = lambda d: d[0] * d[1] * d[2]
+            lay_b = [4.0 * (args.batch * c * (vol(pl.dims[i]) + vol(pl.dims[i + 1])) + c * 27) for i, c in enumerate(chans)]
+            lay_us = [1e3 * sum(dw_all[f"dw_fwd{i}"]) / len(dw_all[f"dw_fwd{i}"]) for i in range(1, 8)]
+            tot_gbs = sum(lay_b) / (sum(lay_us) * 1e-6) / 1e9
+            out["roofline"]["depthwise_fwd_all_layers"] = {
+                "algorithmic_bytes": sum(lay_b), "sum_launch_us": round(sum(lay_us), 2), "achieved": round(tot_gbs, 1),
+                "frac": round(tot_gbs / HBM_PEAK_GBS, 4), "per_layer_us": [round(u, 2) for u in lay_us],
+                "note": "all seven depthwise forwards of one step, HIP events in situ, separate 20-step pass"}
         print(f"host enqueue {t_host / args.steps * 1e3:.3f} ms/step of {dt / args.steps * 1e3:.3f} ms/step wall; "
               f"one step into empty queues: {t_host1 * 1e3:.3f} ms", file=sys.stderr)
         if args.profile_all:

@@ -93,7 +93,7 @@ int msl_stem_conv_bwd_weight_fused(const float* dz, const float* w1_t, const flo
 
 /* ---- depthwise Conv3d(C,C,k3,stride s,p1,groups=C) : Block.conv1, mobilenet.py:38,44 ---------------------- */
 int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride);
-int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride); /* 0 naive, 1 stream, 2 resident */
+int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride); /* 0 naive, 1 stream, 2 resident, 3 wave */
 int msl_dwconv_fwd(const float* x, const float* in_scale, const float* in_shift, const float* w, float* y,
                    double* partials, int N, int C, int D, int H, int W, int stride, int force_naive, void* stream);
 /* stride-1 bwd-data as a forward pass with reversed taps on the LDS-resident kernel (-2 if the shape is not on that path) */

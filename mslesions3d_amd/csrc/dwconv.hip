@@ -545,6 +545,174 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// "wave" variant: stride 1 on planes of 4x4 / 8x8 / 16x16 (the tail of the network, where a whole plane is <= 64
+// float4).  A wave owns SL output planes of CPW = 64 / (H*W/4) channels and keeps its SL+2 input planes in
+// registers: one float4 per lane and plane, every load of the wave in flight at once.  The row above / below is
+// the lane W/4 away and the column neighbours sit in the adjacent lanes, so the 3x3 window comes from DPP lane
+// shifts (ds_bpermute for the 16x16 plane, whose 4-lane rows cross the 16-lane DPP rows).  No LDS tile, no
+// barrier, no integer division per element; waves are independent.
+template <int S>
+__device__ __forceinline__ float lane_minus(float v, int lane) {  // value held by lane - S (caller masks lanes without one)
+  if constexpr (S == 1) return msl::dpp_mov<0x111>(v);       // row_shr:1
+  else if constexpr (S == 2) return msl::dpp_mov<0x112>(v);  // row_shr:2
+  else return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane - S) & 63) << 2, __float_as_int(v)));
+}
+template <int S>
+__device__ __forceinline__ float lane_plus(float v, int lane) {
+  if constexpr (S == 1) return msl::dpp_mov<0x101>(v);       // row_shl:1
+  else if constexpr (S == 2) return msl::dpp_mov<0x102>(v);  // row_shl:2
+  else return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + S) & 63) << 2, __float_as_int(v)));
+}
+
+template <int LOGW4, int LOGH, int SL>
+__global__ __launch_bounds__(256) void dw_s1_wave_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int nslabs,
+    int Nbatch, int flip, int accumulate, msl::BnFold fold) {
+  constexpr int W4 = 1 << LOGW4, H = 1 << LOGH, P4 = W4 * H, CPW = 64 / P4, W = 4 * W4, HW = H * W, NPL = SL + 2;
+  const int lane = threadIdx.x & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int CG = C / CPW;
+  if (gw >= Nbatch * CG * nslabs) return;  // whole wave
+  const int slab = gw % nslabs, vg = gw / nslabs;
+  const int n = vg / CG, c0 = (vg % CG) * CPW;
+  const int cl = CPW == 1 ? 0 : lane >> (LOGW4 + LOGH);
+  const int h = (lane >> LOGW4) & (H - 1), w4 = lane & (W4 - 1);
+  const int c = c0 + cl;
+  const int od0 = slab * SL;
+
+  // every input plane of the wave leaves first (unconditional, on clamped plane indices; masked below)
+  const float* xc = x + (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
+  float4 pv[NPL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = min(max(od0 - 1 + i, 0), D - 1);
+    pv[i] = *reinterpret_cast<const float4*>(xc + (size_t)p * HW);
+  }
+  float wk[27];  // CPW == 1: the channel is wave-uniform and the taps are scalar loads
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = w[(size_t)c * 27 + (flip ? 26 - k : k)];
+
+  const bool affine = in_scale != nullptr || fold.partials != nullptr;
+  float sc = 1.f, sh = 0.f;
+  if (fold.partials) {
+    float m_, i_;
+    double v_;
+    if (fold.NP <= 64) {
+      msl::bn_fold_serial(fold, c, sc, sh, m_, i_, v_);  // lanes of a channel repeat the same (broadcast) loads
+    } else {
+      for (int k = 0; k < CPW; ++k) {
+        float a, b;
+        msl::bn_fold_wave(fold, c0 + k, a, b, m_, i_, v_);
+        if (cl == k) {
+          sc = a;
+          sh = b;
+        }
+      }
+    }
+  } else if (in_scale) {
+    sc = in_scale[c];
+    sh = in_shift[c];
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) msl::pin(pv[i]);
+
+  const bool up_ok = h > 0, dn_ok = h < H - 1, lf_ok = w4 > 0, rt_ok = w4 < W4 - 1;
+  float acc[SL][4];
+#pragma unroll
+  for (int o = 0; o < SL; ++o)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[o][v] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = od0 - 1 + i;
+    if (p < 0 || p >= D) continue;  // wave-uniform: a zero plane adds nothing
+    float4 m = pv[i];
+    if (affine) {
+      m.x = msl::act(m.x, sc, sh); m.y = msl::act(m.y, sc, sh);
+      m.z = msl::act(m.z, sc, sh); m.w = msl::act(m.w, sc, sh);
+    }
+    // R[kh][0..5] = columns (4*w4 - 1) .. (4*w4 + 4) of input row h - 1 + kh
+    float R[3][6];
+    R[1][1] = m.x; R[1][2] = m.y; R[1][3] = m.z; R[1][4] = m.w;
+    {
+      const float a = lane_minus<W4>(m.x, lane), b = lane_minus<W4>(m.y, lane);
+      const float cc = lane_minus<W4>(m.z, lane), d = lane_minus<W4>(m.w, lane);
+      R[0][1] = up_ok ? a : 0.f; R[0][2] = up_ok ? b : 0.f; R[0][3] = up_ok ? cc : 0.f; R[0][4] = up_ok ? d : 0.f;
+    }
+    {
+      const float a = lane_plus<W4>(m.x, lane), b = lane_plus<W4>(m.y, lane);
+      const float cc = lane_plus<W4>(m.z, lane), d = lane_plus<W4>(m.w, lane);
+      R[2][1] = dn_ok ? a : 0.f; R[2][2] = dn_ok ? b : 0.f; R[2][3] = dn_ok ? cc : 0.f; R[2][4] = dn_ok ? d : 0.f;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      if constexpr (W4 > 1) {
+        const float l = lane_minus<1>(R[kh][4], lane), r = lane_plus<1>(R[kh][1], lane);
+        R[kh][0] = lf_ok ? l : 0.f;
+        R[kh][5] = rt_ok ? r : 0.f;
+      } else {
+        R[kh][0] = 0.f;
+        R[kh][5] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int o = i - kd;  // output plane od0 + o reads input plane od0 + o - 1 + kd
+      if (o < 0 || o >= SL) continue;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float ww = wk[kd * 9 + kh * 3 + kw];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[o][v] = fmaf(ww, R[kh][v + kw], acc[o][v]);
+        }
+    }
+  }
+
+  double ds = 0.0, dq = 0.0;
+  float* yc = y + (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    const int od = od0 + o;
+    if (od >= D) continue;  // wave-uniform (ragged last slab)
+    float* yo = yc + (size_t)od * HW;
+    if (accumulate) {
+      const float4 old = *reinterpret_cast<const float4*>(yo);
+      acc[o][0] += old.x; acc[o][1] += old.y; acc[o][2] += old.z; acc[o][3] += old.w;
+    }
+    *reinterpret_cast<float4*>(yo) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+    float s = 0.f, q = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+      s += acc[o][v];
+      q = fmaf(acc[o][v], acc[o][v], q);
+    }
+    ds += (double)s;
+    dq += (double)q;
+  }
+  if (partials) {
+    if constexpr (P4 == 64) {
+      ds = msl::wave_sum(ds);
+      dq = msl::wave_sum(dq);
+    } else if constexpr (P4 == 16) {
+      ds = msl::row16_sum(ds);
+      dq = msl::row16_sum(dq);
+    } else {
+      ds += msl::dpp_mov<0xB1>(ds); ds += msl::dpp_mov<0x4E>(ds);
+      dq += msl::dpp_mov<0xB1>(dq); dq += msl::dpp_mov<0x4E>(dq);
+    }
+    if ((lane & (P4 - 1)) == 0) {
+      const int NP = Nbatch * nslabs, pidx = n * nslabs + slab;
+      partials[(size_t)c * NP + pidx] = ds;
+      partials[((size_t)C + c) * NP + pidx] = dq;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Generic fallback (any W, any plane size): one output per thread straight from global memory.
 __global__ __launch_bounds__(256) void dw_fwd_naive_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
@@ -636,7 +804,7 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
   const int RS = stride == 1 ? W + 8 : ((OW + 3) & ~3) + ((OW + 4) & ~3);
   const int PS = (H + 2) * RS;
   const int OWV = OW / 4, Lp = OH * OWV;
-  static const int stream_min_hw = getenv("MSL_DW_STREAM_MIN_HW") ? atoi(getenv("MSL_DW_STREAM_MIN_HW")) : 1025;
+  static const int stream_min_hw = getenv("MSL_DW_STREAM_MIN_HW") ? atoi(getenv("MSL_DW_STREAM_MIN_HW")) : 1024;
   if (H * W >= stream_min_hw) {  // stream
     int G = 1;
     int ipt = msl::cdiv(G * Lp, 256);
@@ -691,6 +859,50 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
   return pl;
 }
 
+// Register-marching wave kernel (dw_s1_wave_kernel): stride 1, square planes of 4 / 8 / 16.  Two depth slabs per
+// cube of the network's tail (NP = 2N partials per channel, as the resident plan had).
+struct WavePlan {
+  bool ok;
+  int logw4, logh, cpw, SL, nslabs;
+};
+
+WavePlan make_wave_plan(int N, int C, int D, int H, int W, int stride) {
+  static const int enabled = getenv("MSL_DW_WAVE") ? atoi(getenv("MSL_DW_WAVE")) : 1;
+  WavePlan wp{};
+  if (!enabled || stride != 1 || H != W || (W != 4 && W != 8 && W != 16)) return wp;
+  wp.logw4 = W == 4 ? 0 : W == 8 ? 1 : 2;
+  wp.logh = wp.logw4 + 2;
+  wp.cpw = 64 / (H * W / 4);
+  if (C % wp.cpw != 0) return wp;
+  wp.SL = D >= 16 ? 8 : D >= 8 ? 4 : D >= 4 ? 2 : 1;
+  wp.nslabs = msl::cdiv(D, wp.SL);
+  if ((long long)N * (C / wp.cpw) * wp.nslabs > (1ll << 30)) return wp;
+  wp.ok = true;
+  return wp;
+}
+
+void launch_wave(const WavePlan& wp, const float* x, const float* in_scale, const float* in_shift, const float* w,
+                 float* y, double* partials, int N, int C, int D, int flip, int accumulate, const msl::BnFold& fold,
+                 hipStream_t st) {
+  const int waves = N * (C / wp.cpw) * wp.nslabs;
+  const dim3 grid(msl::cdiv(waves, 4)), block(256);
+#define MSL_DW_WAVE_SL(LW_, LH_)                                                                                  \
+  switch (wp.SL) {                                                                                                \
+    case 8: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 8>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+                               partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
+    case 4: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+                               partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
+    case 2: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+                               partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
+    default: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+                                partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                     \
+  }
+  if (wp.logw4 == 0) { MSL_DW_WAVE_SL(0, 2) }
+  else if (wp.logw4 == 1) { MSL_DW_WAVE_SL(1, 3) }
+  else { MSL_DW_WAVE_SL(2, 4) }
+#undef MSL_DW_WAVE_SL
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) {
@@ -706,11 +918,14 @@ int set_lds(K kernel, size_t bytes) {
 extern "C" {
 
 int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride) {
+  const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+  if (wp.ok) return N * wp.nslabs;
   return make_plan(N, C, D, H, W, stride).num_partials;
 }
 
-// variant actually chosen for a shape (0 naive, 1 stream, 2 resident) — for tests / DESIGN.md
+// variant actually chosen for a shape (0 naive, 1 stream, 2 resident, 3 wave) — for tests / DESIGN.md
 int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride) {
+  if (make_wave_plan(N, C, D, H, W, stride).ok) return 3;
   return make_plan(N, C, D, H, W, stride).variant;
 }
 
@@ -771,6 +986,12 @@ int msl_dwconv_bwd_weight_tiled_num_partials(int N, int C, int D, int H, int W, 
 // forward kernel.  Returns MSL_ERR_UNSUPPORTED when the shape is not on the resident fast path.
 int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in, int N, int C, int D, int H, int W,
                                     int accumulate, void* stream) {
+  const WavePlan wp = make_wave_plan(N, C, D, H, W, 1);
+  if (wp.ok) {
+    launch_wave(wp, dy, nullptr, nullptr, w, g_in, nullptr, N, C, D, 1, accumulate, nofold, (hipStream_t)stream);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
   DwPlan pl = make_plan(N, C, D, H, W, 1);
   if (pl.variant != 2) return MSL_ERR_UNSUPPORTED;
   const int nblocks = N * (C / pl.G) * pl.nslabs;
@@ -787,8 +1008,16 @@ static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* i
                            int force_naive, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
-  DwPlan pl = make_plan(N, C, D, H, W, stride);
   hipStream_t st = (hipStream_t)stream;
+  if (!force_naive) {
+    const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+    if (wp.ok) {
+      launch_wave(wp, x, in_scale, in_shift, w, y, partials, N, C, D, 0, 0, fold, st);
+      MSL_LAUNCH_CHECK();
+      return MSL_OK;
+    }
+  }
+  DwPlan pl = make_plan(N, C, D, H, W, stride);
   if (force_naive && pl.variant != 0) {
     pl.variant = 0;
     pl.num_partials = N * msl::cdiv(OD * OH * OW, STATS_CHUNK);

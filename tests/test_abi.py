@@ -58,7 +58,9 @@ def test_pure_host_entry_points():
     # shape planning helpers are host-only arithmetic: config A (128^3, batch 4) of BASELINE.json
     assert lib.msl_stem_conv_fwd_num_partials(4, 64, 64, 64) == 4 * 256
     assert lib.msl_dwconv_fwd_variant(4, 32, 64, 64, 64, 2) == 1   # L1: streamed planes
-    assert lib.msl_dwconv_fwd_variant(4, 64, 32, 32, 32, 2) == 2   # L2: LDS-resident slab
+    assert lib.msl_dwconv_fwd_variant(4, 64, 32, 32, 32, 2) == 1   # L2: streamed planes
+    assert lib.msl_dwconv_fwd_variant(4, 128, 16, 16, 16, 2) == 2  # L4: LDS-resident slab
+    assert lib.msl_dwconv_fwd_variant(4, 128, 16, 16, 16, 1) == 3  # L3: planes in registers, one wave per slab
     assert lib.msl_dwconv_fwd_variant(2, 512, 2, 2, 2, 1) == 0     # 64^3 config tail: generic kernel
     assert lib.msl_pwconv_fwd_num_partials(4, 32, 64, 32768) == 4 * 128   # two 32-column tiles per wave
     assert lib.msl_pwconv_fwd_num_partials(4, 512, 512, 64) == 4 * 2      # K-split wave form: 32-column tiles
