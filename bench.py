@@ -87,6 +87,7 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    from mslesions3d_amd import _lib
     from mslesions3d_amd.parallel import broadcast_model
     from mslesions3d_amd.ssd3d import LSSD3D, MultiBoxLoss
     from mslesions3d_amd.synth import make_batch_on_device
@@ -172,10 +173,14 @@ def main():
         ms = prof.get("dw_fwd1", [])
         avg_ms = sum(ms) / max(len(ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if ms else None
+        variant = _lib.load().msl_dwconv_fwd_variant(args.batch, C1, *d0, 2)
+        dw1_kernel = {3: "dw_s2_wave_kernel<4,5,4>", 1: "dw_fwd_stream_kernel<2,1,4,0>"}.get(variant, f"dwconv variant {variant}")
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "dw_fwd1_traffic.json")
-        if os.path.exists(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        if os.path.exists(tpath):  # PMC bytes per launch of THIS kernel (tools/summarize_profiles.py), else null
+            tj = json.load(open(tpath))
+            if tj.get("kernel", "").replace(" ", "") == dw1_kernel:
+                traffic = tj.get("hbm_bytes_per_launch")
         out = {
             "metric": "training volumes/sec at 128^3 batch-4 (fwd+loss+bwd+Adam), data-parallel over N MI355X",
             "value": round(value, 2), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -185,7 +190,7 @@ def main():
                                    f"SSD3D+MobileNet3D full train step (BASELINE configs[1]/[2] shape)",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "priors": pl.P,
                        "last_loss": {"conf": conf, "loc": loc, "n_positives": npos}},
-            "roofline": {"bound": "hbm", "kernel": "dw_fwd_stream_kernel<2,1,4> (depthwise 3x3x3 s2 forward, block 1)",
+            "roofline": {"bound": "hbm", "kernel": dw1_kernel + " (depthwise 3x3x3 s2 forward, block 1)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,

@@ -712,6 +712,157 @@ __global__ __launch_bounds__(256) void dw_s1_wave_kernel(
   }
 }
 
+// Stride-2 sibling.  A lane owns one "cell" = output row oh x two adjacent outputs (ow = 2*w4, 2*w4+1) and loads the
+// three input rows 2oh-1, 2oh, 2oh+1 of its float4 column itself (the repeated row is a cache hit), so the only
+// cross-lane value is the column to the left (one DPP shift per row).  Planes of OH * W/4 >= 64 cells are split over
+// several waves (WPP), smaller ones share a wave (CPW channels); a wave keeps the 2*SL+1 input planes of its SL
+// output planes in registers.  Output plane o of the slab takes plane i = 2o + kd of the slab's planes.
+template <int LOGW4, int LOGOH, int SL>
+__global__ __launch_bounds__(256) void dw_s2_wave_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int OD,
+    int nslabs, int Nbatch, msl::BnFold fold) {
+  constexpr int W4 = 1 << LOGW4, OH = 1 << LOGOH, LOGC = LOGW4 + LOGOH, CELLS = 1 << LOGC;
+  constexpr int CPW = CELLS >= 64 ? 1 : 64 / CELLS, WPP = CELLS >= 64 ? CELLS / 64 : 1;
+  constexpr int W = 4 * W4, H = 2 * OH, HW = H * W, OW = 2 * W4, OHW = OH * OW, NPL = 2 * SL + 1;
+  const int lane = threadIdx.x & 63;
+  // the slabs / plane parts of one volume share halo planes and rows: keep them on one XCD (per-XCD L2)
+  const int gw = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
+  const int CG = C / CPW;
+  if (gw >= Nbatch * CG * nslabs * WPP) return;  // whole wave
+  const int part = gw % WPP, t0 = gw / WPP;  // the waves of one plane are neighbours (they share halo rows)
+  const int slab = t0 % nslabs, vg = t0 / nslabs;
+  const int n = vg / CG, c0 = (vg % CG) * CPW;
+  const int cl = CPW == 1 ? 0 : lane >> LOGC;
+  const int cell = CPW == 1 ? part * 64 + lane : lane & (CELLS - 1);
+  const int oh = cell >> LOGW4, w4 = cell & (W4 - 1);
+  const int c = c0 + cl;
+  const int od0 = slab * SL;
+  const bool up_ok = oh > 0, lf_ok = w4 > 0;
+
+  const float* xc = x + (size_t)(n * C + c) * D * HW + w4 * 4;
+  const int row_m = (up_ok ? 2 * oh - 1 : 0) * W, row_0 = 2 * oh * W;
+  float4 pv[NPL][3];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = min(max(2 * od0 - 1 + i, 0), D - 1);
+    const float* xp = xc + (size_t)p * HW;
+    pv[i][0] = *reinterpret_cast<const float4*>(xp + row_m);
+    pv[i][1] = *reinterpret_cast<const float4*>(xp + row_0);
+    pv[i][2] = *reinterpret_cast<const float4*>(xp + row_0 + W);
+  }
+  float wk[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = w[(size_t)c * 27 + k];
+
+  const bool affine = in_scale != nullptr || fold.partials != nullptr;
+  float sc = 1.f, sh = 0.f;
+  if (fold.partials) {
+    float m_, i_;
+    double v_;
+    if (fold.NP <= 64) {
+      msl::bn_fold_serial(fold, c, sc, sh, m_, i_, v_);
+    } else {
+      for (int k = 0; k < CPW; ++k) {
+        float a, b;
+        msl::bn_fold_wave(fold, c0 + k, a, b, m_, i_, v_);
+        if (cl == k) {
+          sc = a;
+          sh = b;
+        }
+      }
+    }
+  } else if (in_scale) {
+    sc = in_scale[c];
+    sh = in_shift[c];
+  }
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) msl::pin(pv[i][r]);
+
+  float acc[SL][2];
+#pragma unroll
+  for (int o = 0; o < SL; ++o) acc[o][0] = acc[o][1] = 0.f;
+
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = 2 * od0 - 1 + i;
+    if (p < 0 || p >= D) continue;  // wave-uniform
+    float T[3][5];  // T[kh][0..4] = columns 4*w4-1 .. 4*w4+3 of input row 2*oh-1+kh
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float4 m = pv[i][r];
+      if (affine) {
+        m.x = msl::act(m.x, sc, sh); m.y = msl::act(m.y, sc, sh);
+        m.z = msl::act(m.z, sc, sh); m.w = msl::act(m.w, sc, sh);
+      }
+      if (r == 0) {  // the row above the first output row is padding
+        m.x = up_ok ? m.x : 0.f; m.y = up_ok ? m.y : 0.f; m.z = up_ok ? m.z : 0.f; m.w = up_ok ? m.w : 0.f;
+      }
+      T[r][1] = m.x; T[r][2] = m.y; T[r][3] = m.z; T[r][4] = m.w;
+      if constexpr (W4 > 1) {
+        const float l = lane_minus<1>(m.w, lane);
+        T[r][0] = lf_ok ? l : 0.f;
+      } else {
+        T[r][0] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      if ((i - kd) % 2 != 0 || i - kd < 0) continue;
+      const int o = (i - kd) / 2;
+      if (o >= SL) continue;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float ww = wk[kd * 9 + kh * 3 + kw];
+          acc[o][0] = fmaf(ww, T[kh][kw], acc[o][0]);
+          acc[o][1] = fmaf(ww, T[kh][kw + 2], acc[o][1]);
+        }
+    }
+  }
+
+  double ds = 0.0, dq = 0.0;
+  float* yc = y + (size_t)(n * C + c) * OD * OHW + oh * OW + 2 * w4;
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    const int od = od0 + o;
+    if (od >= OD) continue;  // wave-uniform (ragged last slab)
+    *reinterpret_cast<float2*>(yc + (size_t)od * OHW) = make_float2(acc[o][0], acc[o][1]);
+    const float s = acc[o][0] + acc[o][1];
+    const float q = fmaf(acc[o][1], acc[o][1], acc[o][0] * acc[o][0]);
+    ds += (double)s;
+    dq += (double)q;
+  }
+  if (partials) {
+    if constexpr (LOGC >= 6) {
+      ds = msl::wave_sum(ds);
+      dq = msl::wave_sum(dq);
+    } else if constexpr (LOGC == 5) {
+      ds = msl::row16_sum(ds);
+      dq = msl::row16_sum(dq);
+      const double s_lo = msl::lane_value(ds, 0) + msl::lane_value(ds, 16), s_hi = msl::lane_value(ds, 32) + msl::lane_value(ds, 48);
+      const double q_lo = msl::lane_value(dq, 0) + msl::lane_value(dq, 16), q_hi = msl::lane_value(dq, 32) + msl::lane_value(dq, 48);
+      ds = lane < 32 ? s_lo : s_hi;
+      dq = lane < 32 ? q_lo : q_hi;
+    } else if constexpr (LOGC == 4) {
+      ds = msl::row16_sum(ds);
+      dq = msl::row16_sum(dq);
+    } else {
+      static_assert(LOGC == 3, "cells per plane: 8, 16, 32 or a multiple of 64");
+      ds += msl::dpp_mov<0xB1>(ds); ds += msl::dpp_mov<0x4E>(ds); ds += msl::dpp_mov<0x141>(ds);  // 8 lanes
+      dq += msl::dpp_mov<0xB1>(dq); dq += msl::dpp_mov<0x4E>(dq); dq += msl::dpp_mov<0x141>(dq);
+    }
+    if ((lane & ((CELLS >= 64 ? 64 : CELLS) - 1)) == 0) {
+      const int NP = Nbatch * nslabs * WPP, pidx = (n * nslabs + slab) * WPP + part;
+      partials[(size_t)c * NP + pidx] = ds;
+      partials[((size_t)C + c) * NP + pidx] = dq;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic fallback (any W, any plane size): one output per thread straight from global memory.
 __global__ __launch_bounds__(256) void dw_fwd_naive_kernel(
@@ -863,18 +1014,40 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
 // cube of the network's tail (NP = 2N partials per channel, as the resident plan had).
 struct WavePlan {
   bool ok;
-  int logw4, logh, cpw, SL, nslabs;
+  int logw4, logh, cpw, SL, nslabs, wpp;  // wpp: waves per plane (stride 2, planes of >= 64 cells)
 };
 
 WavePlan make_wave_plan(int N, int C, int D, int H, int W, int stride) {
-  static const int enabled = getenv("MSL_DW_WAVE") ? atoi(getenv("MSL_DW_WAVE")) : 1;
+  static const int enabled = getenv("MSL_DW_WAVE") ? atoi(getenv("MSL_DW_WAVE")) : 3;  // bit 0: stride 1, bit 1: stride 2
   WavePlan wp{};
-  if (!enabled || stride != 1 || H != W || (W != 4 && W != 8 && W != 16)) return wp;
+  if (!enabled || H != W) return wp;
+  if (stride == 2) {
+    // MSL_DW_WAVE_S2_MAXW=32 sends block 1's 64^2 planes back to the streamed kernel (A/B: tools/ab_dw_wave.sh)
+    static const int maxw = getenv("MSL_DW_WAVE_S2_MAXW") ? atoi(getenv("MSL_DW_WAVE_S2_MAXW")) : 64;
+    if ((W != 8 && W != 16 && W != 32 && W != 64) || W > maxw || !(enabled & 2)) return wp;
+    wp.logw4 = W == 8 ? 1 : W == 16 ? 2 : W == 32 ? 3 : 4;
+    wp.logh = wp.logw4 + 1;  // log2(OH)
+    const int cells = (H / 2) * (W / 4), OD = (D - 1) / 2 + 1;
+    wp.cpw = cells >= 64 ? 1 : 64 / cells;
+    wp.wpp = cells >= 64 ? cells / 64 : 1;
+    if (C % wp.cpw != 0) return wp;
+    wp.SL = OD >= 8 ? 4 : OD >= 4 ? 2 : 1;
+    static const int sl2 = getenv("MSL_DW_WAVE_SL2") ? atoi(getenv("MSL_DW_WAVE_SL2")) : 0;  // tuning knob: cap
+    if (sl2 > 0) wp.SL = std::min(wp.SL, sl2 >= 4 ? 4 : sl2 >= 2 ? 2 : 1);
+    wp.nslabs = msl::cdiv(OD, wp.SL);
+    if ((long long)N * (C / wp.cpw) * wp.nslabs * wp.wpp > (1ll << 30)) return wp;
+    wp.ok = true;
+    return wp;
+  }
+  wp.wpp = 1;
+  if (!(enabled & 1) || stride != 1 || (W != 4 && W != 8 && W != 16)) return wp;
   wp.logw4 = W == 4 ? 0 : W == 8 ? 1 : 2;
   wp.logh = wp.logw4 + 2;
   wp.cpw = 64 / (H * W / 4);
   if (C % wp.cpw != 0) return wp;
   wp.SL = D >= 16 ? 8 : D >= 8 ? 4 : D >= 4 ? 2 : 1;
+  static const int sl1 = getenv("MSL_DW_WAVE_SL1") ? atoi(getenv("MSL_DW_WAVE_SL1")) : 0;  // tuning knob: cap
+  if (sl1 > 0) wp.SL = std::min(wp.SL, sl1 >= 8 ? 8 : sl1 >= 4 ? 4 : sl1 >= 2 ? 2 : 1);
   wp.nslabs = msl::cdiv(D, wp.SL);
   if ((long long)N * (C / wp.cpw) * wp.nslabs > (1ll << 30)) return wp;
   wp.ok = true;
@@ -903,6 +1076,26 @@ void launch_wave(const WavePlan& wp, const float* x, const float* in_scale, cons
 #undef MSL_DW_WAVE_SL
 }
 
+void launch_wave_s2(const WavePlan& wp, const float* x, const float* in_scale, const float* in_shift, const float* w,
+                    float* y, double* partials, int N, int C, int D, const msl::BnFold& fold, hipStream_t st) {
+  const int waves = N * (C / wp.cpw) * wp.nslabs * wp.wpp, OD = (D - 1) / 2 + 1;
+  const dim3 grid(msl::cdiv(waves, 4)), block(256);
+#define MSL_DW_WAVE2_SL(LW_, LH_)                                                                                  \
+  switch (wp.SL) {                                                                                                 \
+    case 4: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
+                               partials, C, D, OD, wp.nslabs, N, fold); break;                                     \
+    case 2: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
+                               partials, C, D, OD, wp.nslabs, N, fold); break;                                     \
+    default: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+                                partials, C, D, OD, wp.nslabs, N, fold); break;                                    \
+  }
+  if (wp.logw4 == 1) { MSL_DW_WAVE2_SL(1, 2) }
+  else if (wp.logw4 == 2) { MSL_DW_WAVE2_SL(2, 3) }
+  else if (wp.logw4 == 3) { MSL_DW_WAVE2_SL(3, 4) }
+  else { MSL_DW_WAVE2_SL(4, 5) }
+#undef MSL_DW_WAVE2_SL
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) {
@@ -919,7 +1112,7 @@ extern "C" {
 
 int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride) {
   const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
-  if (wp.ok) return N * wp.nslabs;
+  if (wp.ok) return N * wp.nslabs * wp.wpp;
   return make_plan(N, C, D, H, W, stride).num_partials;
 }
 
@@ -1012,7 +1205,8 @@ static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* i
   if (!force_naive) {
     const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
     if (wp.ok) {
-      launch_wave(wp, x, in_scale, in_shift, w, y, partials, N, C, D, 0, 0, fold, st);
+      if (stride == 2) launch_wave_s2(wp, x, in_scale, in_shift, w, y, partials, N, C, D, fold, st);
+      else launch_wave(wp, x, in_scale, in_shift, w, y, partials, N, C, D, 0, 0, fold, st);
       MSL_LAUNCH_CHECK();
       return MSL_OK;
     }

@@ -57,9 +57,11 @@ def test_pure_host_entry_points():
     assert lib.msl_abi_version() == 1
     # shape planning helpers are host-only arithmetic: config A (128^3, batch 4) of BASELINE.json
     assert lib.msl_stem_conv_fwd_num_partials(4, 64, 64, 64) == 4 * 256
-    assert lib.msl_dwconv_fwd_variant(4, 32, 64, 64, 64, 2) == 1   # L1: streamed planes
-    assert lib.msl_dwconv_fwd_variant(4, 64, 32, 32, 32, 2) == 1   # L2: streamed planes
-    assert lib.msl_dwconv_fwd_variant(4, 128, 16, 16, 16, 2) == 2  # L4: LDS-resident slab
+    assert lib.msl_dwconv_fwd_variant(4, 32, 64, 64, 64, 2) == 3   # L1: planes in registers, eight waves per plane
+    assert lib.msl_dwconv_fwd_variant(2, 32, 96, 96, 96, 2) == 1   # 192^3 inference, L1: streamed planes
+    assert lib.msl_dwconv_fwd_variant(4, 64, 32, 32, 32, 2) == 3   # L2: planes in registers, two waves per plane
+    assert lib.msl_dwconv_fwd_variant(2, 128, 24, 24, 24, 1) == 2  # 192^3 inference, L3: LDS-resident slab
+    assert lib.msl_dwconv_fwd_variant(4, 128, 16, 16, 16, 2) == 3  # L4: planes in registers
     assert lib.msl_dwconv_fwd_variant(4, 128, 16, 16, 16, 1) == 3  # L3: planes in registers, one wave per slab
     assert lib.msl_dwconv_fwd_variant(2, 512, 2, 2, 2, 1) == 0     # 64^3 config tail: generic kernel
     assert lib.msl_pwconv_fwd_num_partials(4, 32, 64, 32768) == 4 * 128   # two 32-column tiles per wave

@@ -95,8 +95,11 @@ def test_stem_bwd_weight(cin, dims, stride):
 # ------------------------------------------------------------------------------------------------- depthwise
 DW_CASES = [  # (N, C, dims, stride, expected variant)
     (1, 4, (10, 40, 40), 2, 1), (1, 3, (9, 40, 48), 1, 1), (1, 2, (7, 96, 96), 2, 1),
-    (2, 8, (16, 16, 16), 2, 2), (2, 64, (8, 8, 8), 2, 2), (2, 16, (32, 16, 32), 2, 2), (1, 4, (6, 12, 16), 1, 2),
-    (2, 16, (32, 32, 32), 2, 1),
+    (2, 16, (32, 16, 32), 2, 2), (1, 4, (6, 12, 16), 1, 2), (2, 8, (12, 24, 24), 2, 2),
+    (1, 2, (6, 64, 64), 2, 3),
+    # register-marching wave kernel, stride 2 (8^2 / 16^2 / 32^2 planes): shared and split planes, odd depth, ragged slab
+    (2, 8, (16, 16, 16), 2, 3), (2, 64, (8, 8, 8), 2, 3), (2, 16, (32, 32, 32), 2, 3), (1, 4, (7, 16, 16), 2, 3),
+    (1, 8, (5, 8, 8), 2, 3), (1, 2, (18, 32, 32), 2, 3), (3, 8, (2, 8, 8), 2, 3),
     # register-marching wave kernel (stride 1, 4^2 / 8^2 / 16^2 planes): every slab length, ragged last slab
     (2, 8, (16, 16, 16), 1, 3), (2, 64, (4, 4, 4), 1, 3), (1, 8, (5, 8, 8), 1, 3), (1, 4, (3, 16, 16), 1, 3),
     (2, 16, (9, 4, 4), 1, 3), (1, 8, (20, 8, 8), 1, 3), (1, 2, (1, 16, 16), 1, 3), (3, 32, (2, 4, 4), 1, 3),
@@ -126,9 +129,12 @@ def test_dw_fwd(N, C, dims, stride, variant, affine):
             close(q, (ref.double() ** 2).sum((0, 2, 3, 4)), 1e-5, 1e-3, "dw sumsq")
 
 
-@pytest.mark.parametrize("N,C,dims,in_np", [(2, 8, (16, 16, 16), 6), (2, 8, (8, 8, 8), 100), (2, 32, (4, 4, 4), 70),
-                                            (1, 16, (5, 4, 4), 9), (2, 4, (6, 12, 16), 70)])
-def test_dw_fwd_fold_matches_explicit_affine(N, C, dims, in_np):
+@pytest.mark.parametrize("N,C,dims,in_np,stride", [(2, 8, (16, 16, 16), 6, 1), (2, 8, (8, 8, 8), 100, 1),
+                                                   (2, 32, (4, 4, 4), 70, 1), (1, 16, (5, 4, 4), 9, 1),
+                                                   (2, 4, (6, 12, 16), 70, 1), (2, 16, (8, 8, 8), 70, 2),
+                                                   (2, 4, (8, 16, 16), 5, 2), (1, 2, (8, 32, 32), 130, 2),
+                                                   (1, 2, (6, 64, 64), 70, 2), (1, 2, (5, 96, 96), 70, 2)])
+def test_dw_fwd_fold_matches_explicit_affine(N, C, dims, in_np, stride):
     """The in-kernel BatchNorm fold (serial for NP <= 64, wave tree above) gives the bits of finalize + explicit vectors."""
     L = _lib.load()
     x, w = rnd(N, C, *dims, seed=14), rnd(C, 1, 3, 3, 3, seed=15, scale=0.4)
@@ -143,22 +149,22 @@ def test_dw_fwd_fold_matches_explicit_affine(N, C, dims, in_np):
     nbt = torch.zeros(1, dtype=torch.int64, device=DEV)
     _lib.call("msl_bn_finalize", ptr(part_in), in_np, count, ptr(K(gamma)), ptr(K(beta)), ptr(rm), ptr(rv), ptr(nbt), 0.1,
               1e-5, ptr(vec), ptr(vec[C:]), ptr(vec[2 * C:]), ptr(vec[3 * C:]), C, st())
-    NP = L.msl_dwconv_fwd_num_partials(N, C, *dims, 1)
+    NP = L.msl_dwconv_fwd_num_partials(N, C, *dims, stride)
     out = []
     for fold in (False, True):
-        y = torch.full((N, C, *dims), float("nan"), device=DEV)
+        y = torch.full((N, C) + tuple((d - 1) // stride + 1 for d in dims), float("nan"), device=DEV)
         part = torch.zeros(2 * C * NP, dtype=torch.float64, device=DEV)
         if fold:
             _lib.call("msl_dwconv_fwd_fold", ptr(K(x)), ptr(part_in), in_np, count, ptr(K(gamma)), ptr(K(beta)), 1e-5,
-                      ptr(K(w)), ptr(y), ptr(part), N, C, *dims, 1, st())
+                      ptr(K(w)), ptr(y), ptr(part), N, C, *dims, stride, st())
         else:
-            _lib.call("msl_dwconv_fwd", ptr(K(x)), ptr(vec), ptr(vec[C:]), ptr(K(w)), ptr(y), ptr(part), N, C, *dims, 1,
-                      0, st())
+            _lib.call("msl_dwconv_fwd", ptr(K(x)), ptr(vec), ptr(vec[C:]), ptr(K(w)), ptr(y), ptr(part), N, C, *dims,
+                      stride, 0, st())
         out.append((y, part))
     torch.cuda.synchronize()
     assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
     sc, sh = vec[:C].cpu(), vec[C:2 * C].cpu()
-    ref = F.conv3d(affine_act(x, sc, sh), w, stride=1, padding=1, groups=C)
+    ref = F.conv3d(affine_act(x, sc, sh), w, stride=stride, padding=1, groups=C)
     close(out[1][0], ref, 1e-5, 1e-5, "dw fwd fold")
 
 
