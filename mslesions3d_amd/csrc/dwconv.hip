@@ -717,19 +717,27 @@ __global__ __launch_bounds__(256) void dw_s1_wave_kernel(
 // cross-lane value is the column to the left (one DPP shift per row).  Planes of OH * W/4 >= 64 cells are split over
 // several waves (WPP), smaller ones share a wave (CPW channels); a wave keeps the 2*SL+1 input planes of its SL
 // output planes in registers.  Output plane o of the slab takes plane i = 2o + kd of the slab's planes.
+template <int LOGW4, int LOGOH>
+constexpr int s2_wave_block() {  // threads per workgroup: up to four waves of a split plane, else four independent waves
+  return (1 << (LOGW4 + LOGOH)) == 128 ? 128 : 256;
+}
+
 template <int LOGW4, int LOGOH, int SL>
-__global__ __launch_bounds__(256) void dw_s2_wave_kernel(
+__global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_kernel(
     const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
     const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int OD,
     int nslabs, int Nbatch, msl::BnFold fold) {
   constexpr int W4 = 1 << LOGW4, OH = 1 << LOGOH, LOGC = LOGW4 + LOGOH, CELLS = 1 << LOGC;
   constexpr int CPW = CELLS >= 64 ? 1 : 64 / CELLS, WPP = CELLS >= 64 ? CELLS / 64 : 1;
   constexpr int W = 4 * W4, H = 2 * OH, HW = H * W, OW = 2 * W4, OHW = OH * OW, NPL = 2 * SL + 1;
+  // the waves of a split plane form workgroups of up to four (eight-wave workgroups at ~150 VGPRs cost occupancy:
+  // 38 us instead of 31 us on block 1); a workgroup's statistics are summed in LDS -> WPP / WPG partials per plane slab
+  constexpr int WPG = WPP == 1 ? 4 : (WPP < 4 ? WPP : 4), GPP = WPP == 1 ? 1 : WPP / WPG;
   const int lane = threadIdx.x & 63;
   // the slabs / plane parts of one volume share halo planes and rows: keep them on one XCD (per-XCD L2)
-  const int gw = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
+  const int gw = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPG + (threadIdx.x >> 6));
   const int CG = C / CPW;
-  if (gw >= Nbatch * CG * nslabs * WPP) return;  // whole wave
+  if (WPP == 1 && gw >= Nbatch * CG * nslabs) return;  // whole wave (WPP > 1: the grid is exact)
   const int part = gw % WPP, t0 = gw / WPP;  // the waves of one plane are neighbours (they share halo rows)
   const int slab = t0 % nslabs, vg = t0 / nslabs;
   const int n = vg / CG, c0 = (vg % CG) * CPW;
@@ -837,7 +845,28 @@ __global__ __launch_bounds__(256) void dw_s2_wave_kernel(
     dq += (double)q;
   }
   if (partials) {
-    if constexpr (LOGC >= 6) {
+    if constexpr (WPP > 1) {
+      __shared__ double red[2][WPG];
+      ds = msl::wave_sum(ds);
+      dq = msl::wave_sum(dq);
+      if (lane == 0) {
+        red[0][part % WPG] = ds;
+        red[1][part % WPG] = dq;
+      }
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        double s = 0.0, q = 0.0;
+#pragma unroll
+        for (int k = 0; k < WPG; ++k) {
+          s += red[0][k];
+          q += red[1][k];
+        }
+        const int NP = Nbatch * nslabs * GPP, pidx = (n * nslabs + slab) * GPP + part / WPG;
+        partials[(size_t)c * NP + pidx] = s;
+        partials[((size_t)C + c) * NP + pidx] = q;
+      }
+      return;
+    } else if constexpr (LOGC == 6) {
       ds = msl::wave_sum(ds);
       dq = msl::wave_sum(dq);
     } else if constexpr (LOGC == 5) {
@@ -856,7 +885,7 @@ __global__ __launch_bounds__(256) void dw_s2_wave_kernel(
       dq += msl::dpp_mov<0xB1>(dq); dq += msl::dpp_mov<0x4E>(dq); dq += msl::dpp_mov<0x141>(dq);
     }
     if ((lane & ((CELLS >= 64 ? 64 : CELLS) - 1)) == 0) {
-      const int NP = Nbatch * nslabs * WPP, pidx = (n * nslabs + slab) * WPP + part;
+      const int NP = Nbatch * nslabs, pidx = n * nslabs + slab;
       partials[(size_t)c * NP + pidx] = ds;
       partials[((size_t)C + c) * NP + pidx] = dq;
     }
@@ -1079,7 +1108,8 @@ void launch_wave(const WavePlan& wp, const float* x, const float* in_scale, cons
 void launch_wave_s2(const WavePlan& wp, const float* x, const float* in_scale, const float* in_shift, const float* w,
                     float* y, double* partials, int N, int C, int D, const msl::BnFold& fold, hipStream_t st) {
   const int waves = N * (C / wp.cpw) * wp.nslabs * wp.wpp, OD = (D - 1) / 2 + 1;
-  const dim3 grid(msl::cdiv(waves, 4)), block(256);
+  const int wpg = wp.wpp > 1 ? std::min(wp.wpp, 4) : 4;
+  const dim3 grid(msl::cdiv(waves, wpg)), block(64 * wpg);
 #define MSL_DW_WAVE2_SL(LW_, LH_)                                                                                  \
   switch (wp.SL) {                                                                                                 \
     case 4: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
@@ -1112,7 +1142,7 @@ extern "C" {
 
 int msl_dwconv_fwd_num_partials(int N, int C, int D, int H, int W, int stride) {
   const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
-  if (wp.ok) return N * wp.nslabs * wp.wpp;
+  if (wp.ok) return N * wp.nslabs * (wp.wpp > 4 ? wp.wpp / 4 : 1);
   return make_plan(N, C, D, H, W, stride).num_partials;
 }
 
