@@ -5,7 +5,11 @@
 // (relu(fma(x, scale[c], shift[c]))), so the normalised activation never exists in HBM.  The kernel
 // also emits fp64 (sum, sumsq) partials of its own raw output for the following BatchNorm.
 //
-// Two MI355X shapes of the same algorithm (HBM-bound: ~1.5-6.7 flop/B):
+// Three MI355X shapes of the same algorithm (HBM-bound: ~1.5-6.7 flop/B):
+//  * "wave" (square power-of-two planes: every depthwise layer of the 128^3 / 64^3 configurations): the input planes
+//    of a wave's output slab live in registers, row / column neighbours come from DPP lane shifts or from the lane's
+//    own second and third row load - no LDS tile, no barrier, every load of the wave in flight at once
+//    (dw_s1_wave_kernel, dw_s2_wave_kernel below).
 //  * "stream" (large H x W planes, e.g. 64^2 at 128^3): a workgroup owns a slab of output planes of one
 //    (n, c) volume.  Input planes are streamed once through LDS (16-B coalesced global loads along W,
 //    next plane prefetched into registers while the current one is consumed), each thread keeps the

@@ -4,6 +4,7 @@ Usage: python tools/summarize_profiles.py <tag>"""
 import csv
 import json
 import os
+import re
 import shutil
 import sys
 from collections import defaultdict
@@ -39,7 +40,7 @@ if key:
     fk, wk = fetch[key[0]][0], write[key[0]][0]
     hbm = (2.0 * fk + wk) * 1024.0
     json.dump({
-        "kernel": key[0].split("(")[0].replace("void (anonymous namespace)::", ""), "round": 1, "profile": tag, "FETCH_SIZE_kb_avg": fk, "WRITE_SIZE_kb_avg": wk,
+        "kernel": re.search(r"(\w+<[^>]*>)", key[0]).group(1).replace(" ", ""), "round": 1, "profile": tag, "FETCH_SIZE_kb_avg": fk, "WRITE_SIZE_kb_avg": wk,
         "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming reads -> x2 "
                       "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
         "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 150998400,
