@@ -78,7 +78,12 @@ def main():
     # functional check only - the driver's scaling run uses RCCL, one rank per GPU)
     backend = os.environ.get("MSL_BENCH_BACKEND", "nccl")
     local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
-    if world > 1:
+    rehearse = world == 1 and os.environ.get("MSL_DP_REHEARSE") == "1"  # one-rank RCCL group: DP host/launch cost on 1 GPU
+    if rehearse:
+        os.environ.setdefault("MASTER_PORT", "29577")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or rehearse:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -218,7 +223,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.size, args.batch, args.channels, args.cpu_steps)
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or rehearse:
         dist.destroy_process_group()
 
 

@@ -9,6 +9,8 @@ last), so it is cut into a few contiguous buckets; bucket k is all-reduced on a 
 launches that produce it have been enqueued, overlapping the remaining backward kernels.  3.8 MB is
 latency-bound on xGMI: few large buckets, not many small ones.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -18,6 +20,10 @@ class GradBucketReducer:
         self.arena = arena
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # active: buckets are exchanged.  MSL_DP_REHEARSE=1 runs the whole exchange path (side-stream joins, RCCL launches,
+        # waits) in a one-rank group too: the host and launch cost of data parallelism measured on a single GPU
+        self.active = self.world > 1 or (os.environ.get("MSL_DP_REHEARSE") == "1" and dist.is_available()
+                                         and dist.is_initialized())
         self.ranges = arena.bucket_ranges(n_buckets)
         # stage after which a bucket is complete: 'heads', 7, 6, ..., 0 (see Engine.backward)
         stage_of = {}
@@ -35,25 +41,36 @@ class GradBucketReducer:
         self.trigger = {}
         for k, stg in stage_of.items():
             self.trigger.setdefault(stg, []).append(k)
-        self.comm_stream = torch.cuda.Stream() if self.world > 1 and arena.grad.is_cuda else None
+        self.comm_stream = torch.cuda.Stream() if self.active and arena.grad.is_cuda else None
         self.pending = []
+        self.final_on_main = True  # stage 0 (everything joined) is exchanged on the caller's stream, see on_stage
+        self.presynced = False  # set by a caller that already made comm_stream wait for the bucket's producers
         # Engine.backward only reports (and joins its side streams for) the stages that complete a bucket
-        self.stages = set(self.trigger.keys()) if self.world > 1 else set()
+        self.stages = set(self.trigger.keys()) if self.active else set()
 
     def __call__(self, stage):
         self.on_stage(stage)
 
     def on_stage(self, stage):
         """Engine.backward calls this right after enqueueing the kernels of ``stage``."""
-        if self.world == 1:
+        if not self.active:
             return
         for k in self.trigger.get(stage, []):
             lo, hi = self.ranges[k]
             view = self.arena.grad[lo:hi]
-            if self.comm_stream is not None:
-                self.comm_stream.wait_stream(torch.cuda.current_stream())
+            if self.comm_stream is not None and stage == 0 and self.final_on_main:
+                # the last bucket (a few KB: first blocks + stem) is complete when every stream has been joined into the
+                # chain, and the optimiser is next: exchange it on the chain's own stream - no cross-queue hand-off
+                # (~16 us each way) in front of Adam
+                dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
+            elif self.comm_stream is not None:
+                if not self.presynced:
+                    self.comm_stream.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(self.comm_stream):
-                    self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                    # stream-ordered form: RCCL's stream waits for comm_stream and comm_stream for the collective, the host
+                    # for nothing.  async_op=True + Work.wait() gives the same ordering but made the whole step 3.3x
+                    # slower on ROCm 7.2 / torch 2.10 (3.4 vs 1.06 ms; tools/probes/dp_host_cost.py)
+                    dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
             else:  # CPU tensors (gloo tests)
                 self.pending.append(dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 

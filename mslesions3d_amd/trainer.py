@@ -61,7 +61,7 @@ class FusedTrainer:
                         with_backward_upstream=st["upstream_alpha"], matched=eng.multi_stream, nan_flag=pl.nan_flag)
         eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red)
         scale = red.finish()
-        if red.world > 1:
+        if red.active:
             _lib.record_hook(red.finish, tag="hook:finish")
         self.opt.step(grad_scale=scale, gather_autograd_grads=False)
         return pl, st
@@ -107,7 +107,7 @@ class FusedTrainer:
                 pl.generation += 1
                 pl.saved_input, pl.trained_mode = images, True
                 self.opt.prepare_step(grad_scale=1.0 / red.world)
-                graph_ok = self.use_graph and red.world == 1
+                graph_ok = self.use_graph and not red.active
                 if eng.prof is not None and graph_ok:
                     # time the tagged launches individually, everything before / after them stays a captured graph
                     tags = frozenset(eng.prof_tags)
