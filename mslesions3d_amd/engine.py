@@ -585,7 +585,11 @@ class Engine:
                 return
             comm = getattr(on_bucket_ready, "comm_stream", None)
             if comm is not None and stage == 0 and getattr(on_bucket_ready, "final_on_main", False):
-                pass  # every stream has just been joined into the chain: the last bucket is exchanged right here
+                # every stream has just been joined into the chain: the last bucket is exchanged right here.  Collectives
+                # of one communicator must not overlap each other, so the chain first waits for the communication stream
+                # (whose buckets were issued ~0.3 ms ago: the wait is normally satisfied on arrival)
+                self._fork(pl, "bucket_tail", comm.cuda_stream, st)
+                on_bucket_ready.presynced = True
             elif comm is not None:
                 # the exchange has a stream of its own: IT waits for the streams that produced the bucket, the
                 # dependency chain never does (joining the weight-gradient stream into the chain three times per step

@@ -61,7 +61,10 @@ class GradBucketReducer:
             if self.comm_stream is not None and stage == 0 and self.final_on_main:
                 # the last bucket (a few KB: first blocks + stem) is complete when every stream has been joined into the
                 # chain, and the optimiser is next: exchange it on the chain's own stream - no cross-queue hand-off
-                # (~16 us each way) in front of Adam
+                # (~16 us each way) in front of Adam.  One communicator = one collective at a time: the earlier buckets on
+                # comm_stream must have finished (the engine records that wait in the launch program)
+                if not self.presynced:
+                    torch.cuda.current_stream().wait_stream(self.comm_stream)
                 dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=False)
             elif self.comm_stream is not None:
                 if not self.presynced:
