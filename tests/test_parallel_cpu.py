@@ -69,3 +69,24 @@ def test_bucketed_allreduce_gloo_world2(tmp_path, n_buckets):
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), n_buckets, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.parametrize("n_buckets", [2, 3, 4])
+def test_bucket_policy_keeps_the_exposed_tail_small(n_buckets):
+    """Only the last bucket's exchange sits in front of the optimiser: it must be the small tail of the gradient (first
+    blocks + stem), complete at stage 0, and every earlier bucket must complete at an earlier backward stage."""
+    from mslesions3d_amd.engine import ParamArena
+    from mslesions3d_amd.parallel import GradBucketReducer
+    from mslesions3d_amd.ssd3d import LSSD3D
+    model = LSSD3D(n_classes=2, input_channels=1, input_size=(64, 64, 64), threshold=[0.1, 0.2])
+    arena = ParamArena(model, torch.device("cpu"))
+    red = GradBucketReducer(arena, n_buckets=n_buckets)
+    assert not red.active and red.world == 1 and red.stages == set()
+    assert len(red.ranges) == n_buckets
+    lo, hi = red.ranges[-1]
+    assert 0 < hi - lo <= 0.05 * arena.n_trainable
+    stage_of = {k: s for s, ks in red.trigger.items() for k in ks}
+    assert stage_of[len(red.ranges) - 1] == 0
+    order = ["heads", 7, 6, 5, 4, 3, 2, 1, 0]
+    pos = [order.index(stage_of[k]) for k in range(len(red.ranges))]
+    assert pos == sorted(pos) and pos[-2] < pos[-1]
