@@ -1,7 +1,7 @@
 """Inference path of BASELINE configs[3] (192^3, batch 2) in fp32: eval forward + decode + 3-D NMS (predict_step),
-timed, then checked against the CPU oracle on the same volumes (keep-lists bit-exact, boxes within 1e-4; the check runs
-last: the oracle's CPU worker threads would otherwise compete with the timed host loop).
-Usage (GPU box): python tools/bench_infer.py [--size 192] [--batch 2] [--no-oracle]"""
+timed.  Parity of this exact workload against the CPU oracle (keep-lists bit-exact, boxes within 1e-4) is
+tests/test_gpu_model.py::test_inference_192_end_to_end_matches_the_oracle.
+Usage (GPU box): python tools/bench_infer.py [--size 192] [--batch 2]"""
 import argparse
 import os
 import sys
@@ -15,7 +15,6 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=192)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
-ap.add_argument("--no-oracle", action="store_true")
 args = ap.parse_args()
 
 from mslesions3d_amd.ssd3d import LSSD3D  # noqa: E402
@@ -52,20 +51,5 @@ dt = time.perf_counter() - t0
 print(f"predict_step: {dt / args.steps * 1e3:.2f} ms per batch of {args.batch} -> {args.batch * args.steps / dt:.0f} volumes/s, "
       f"{nb / dt:.0f} boxes/s (fp32, host sync per batch for the detection counts)")
 
-if not args.no_oracle:
-    from oracle import detect as odet  # noqa: E402  (checker only)
-    from oracle.network import OracleSSD3D  # noqa: E402
-    om = OracleSSD3D(2, 1, size, emulate_reference_init=False)
-    om.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
-    om.eval()
-    t0 = time.perf_counter()
-    with torch.no_grad():
-        ol, osc = om(x.cpu())
-        ob, olab, oscore, oprior = odet.detect_objects(ol, osc, om.priors_cxcycz, return_prior_index=True, **kw)
-    print(f"oracle forward+detect on the CPU: {time.perf_counter() - t0:.1f} s")
-    print(f"locs max err {float((locs.cpu() - ol).abs().max()):.2e}, scores max err {float((scores.cpu() - osc).abs().max()):.2e}")
-    for i in range(args.batch):
-        assert torch.equal(det[3][i].cpu().long(), torch.as_tensor(oprior[i]).long()), f"keep-list differs in volume {i}"
-        err = (det[0][i].cpu() - torch.as_tensor(ob[i])).abs().max().item() if len(ob[i]) else 0.0
-        assert err <= 1e-4, err
-    print("parity: NMS keep-lists bit-exact, boxes within 1e-4")
+# parity of this exact workload against the CPU oracle: tests/test_gpu_model.py::test_inference_192_end_to_end_matches_the_oracle
+# (the oracle is test infrastructure and is not imported from tools/)
