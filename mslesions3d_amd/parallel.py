@@ -89,7 +89,9 @@ class GradBucketReducer:
 
 def broadcast_model(model, src=0, group=None):
     """Initial weights + BatchNorm buffers from rank ``src`` (one flat broadcast for the arena)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size(group) == 1 and os.environ.get("MSL_DP_REHEARSE") != "1":
         return
     arena = getattr(model._engine, "arena", None)
     if arena is not None:
