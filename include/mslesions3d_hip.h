@@ -190,6 +190,17 @@ int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long
                               const float* true_locs, double* workspace, float* loss_out, const float* upstream,
                               float* dlocs, float* dscores, int* nan_flag, int N, int P, int ncls, void* stream);
 
+/* Optional loss variants the reference keeps as commented code (ssd3d.py:758-760 loss choices, :926-932 hard-negative
+ * mining); flags: 1 = hard-negative mining (keep the neg_pos_ratio * n_positives largest negative losses per image),
+ * 2 = smooth-L1 (nn.SmoothL1Loss, beta 1) for the localisation loss, 4 = focal confidence loss (MONAI FocalLoss gamma 2,
+ * weight 0.25, background excluded: two classes only, else MSL_ERR_UNSUPPORTED); 0 = the live path.  Forward, and
+ * backward too when dlocs / dscores are given (upstream as above).  var_ws: ..._var_workspace_bytes(N, P) bytes. */
+size_t msl_multibox_loss_var_workspace_bytes(int N, int P);
+int msl_multibox_loss_var(const float* locs, const float* scores, const long long* true_classes, const float* true_locs,
+                          double* workspace, void* var_ws, float* loss_out, const float* upstream, float* dlocs,
+                          float* dscores, int* nan_flag, int N, int P, int ncls, int flags, int neg_pos_ratio,
+                          void* stream);
+
 /* ---- LSSD3D.detect_objects (ssd3d.py:344-460): softmax, decode, filter, sort, 3D NMS, top-k ---------------
  * cap = 10*top_k (<= 4096), Wn = ceil(cap/64), K1 = ncls-1.  Caller-allocated scratch:
  *   probs (N,K1,P) f32; boxes (N,P,6) f32; sorted_idx (N,K1,cap) i32; ncand (N*K1) i32;

@@ -72,6 +72,8 @@ _SIGNATURES = {
     "msl_multibox_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_multibox_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_multibox_loss_fwd_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_multibox_loss_var_workspace_bytes": (_Z, [_I, _I]),
+    "msl_multibox_loss_var": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msl_detect_select_ws_ints": (_Z, [_I, _I, _I]),
     "msl_detect_objects": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I] + [_P] * 15 + [_P]),
     "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),

@@ -376,6 +376,241 @@ __global__ __launch_bounds__(256) void multibox_loss_bwd_kernel(const float* __r
 
 constexpr int LOSS_BLOCKS = 64;
 
+// ---- optional loss variants (the reference keeps them as commented code, ssd3d.py:760,926-932) ----
+// flags: 1 = hard-negative mining, 2 = smooth-L1 localisation, 4 = focal confidence.  The live path above (flags 0)
+// stays on its own kernels.
+constexpr int VAR_HNM = 1, VAR_SMOOTH = 2, VAR_FOCAL = 4;
+
+// confidence loss of one prior with target class tc >= 0
+__device__ __forceinline__ float conf_value(const float* __restrict__ x, long long tc, int ncls, bool focal) {
+  if (focal) {  // sigmoid focal loss on the foreground logit: 0.25 * (1 - p_t)^2 * BCE   (MONAI FocalLoss, gamma 2)
+    const float z = tc > 0 ? x[1] : -x[1];                          // p_t = sigmoid(z)
+    const float sp = fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)));      // BCE = softplus(-z)
+    const float q = 1.f / (1.f + expf(z));                          // 1 - p_t
+    return 0.25f * q * q * sp;
+  }
+  float m = x[0];
+  for (int c = 1; c < ncls; ++c) m = fmaxf(m, x[c]);
+  float se = 0.f;
+  for (int c = 0; c < ncls; ++c) se += expf(x[c] - m);
+  return (m + logf(se)) - x[tc];
+}
+
+__device__ __forceinline__ unsigned sortable_key(float v) {  // larger float <=> larger key (negative zero / tiny negatives too)
+  const unsigned b = __float_as_uint(v);
+  return b ^ ((b >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+// forward partial sums.  With VAR_HNM the negatives' losses go to conf_all (positives / ignored priors = 0, exactly the
+// reference's conf_loss_neg) and only the positives' confidence loss is summed here.
+__global__ __launch_bounds__(256) void multibox_loss_partial_var_kernel(
+    const float* __restrict__ locs, const float* __restrict__ scores, const long long* __restrict__ true_classes,
+    const float* __restrict__ true_locs, double* __restrict__ partials, float* __restrict__ conf_all, int total,
+    int ncls, int flags, int* __restrict__ nan_flag) {
+  __shared__ double scratch[8];
+  const bool hnm = flags & VAR_HNM, smooth = flags & VAR_SMOOTH, focal = flags & VAR_FOCAL;
+  double ce = 0.0, l1 = 0.0, np = 0.0;
+  bool bad_loc = false, bad_score = false;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    if (nan_flag) {
+      for (int c = 0; c < ncls; ++c) bad_score |= isnan(scores[(size_t)i * ncls + c]);
+#pragma unroll
+      for (int q = 0; q < 6; ++q) bad_loc |= isnan(locs[(size_t)i * 6 + q]);
+    }
+    const long long tc = true_classes[i];
+    float cv = 0.f;
+    if (tc >= 0) cv = conf_value(scores + (size_t)i * ncls, tc, ncls, focal);
+    if (hnm) {
+      conf_all[i] = tc == 0 ? cv : 0.f;
+      if (tc > 0) ce += (double)cv;
+    } else if (tc >= 0) {
+      ce += (double)cv;
+    }
+    if (tc > 0) {
+      np += 1.0;
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const float d = locs[(size_t)i * 6 + q] - true_locs[(size_t)i * 6 + q];
+        const float ad = fabsf(d);
+        a += smooth ? (ad < 1.f ? 0.5f * d * d : ad - 0.5f) : ad;
+      }
+      l1 += (double)a;
+    }
+  }
+  if (nan_flag) {
+    if (__any(bad_loc) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    if (__any(bad_score) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 2);
+  }
+  const double t0 = msl::block_sum(ce, scratch);
+  __syncthreads();
+  const double t1 = msl::block_sum(l1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum(np, scratch);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 3 + 0] = t0;
+    partials[blockIdx.x * 3 + 1] = t1;
+    partials[blockIdx.x * 3 + 2] = t2;
+  }
+}
+
+// Hard-negative mining of one image per workgroup (ssd3d.py:907-908,926-929): among the P entries of conf_loss_neg keep
+// the k = neg_pos_ratio * n_positives largest.  An 8-bit radix select over the sortable keys finds the k-th largest
+// value T; everything above T is kept, and of the entries equal to T the first (k - #above) in index order (what a
+// stable descending sort keeps).  Their sum goes to hnm_sum[n] (fp64, fixed order) and conf_all becomes the 0/1 mask
+// the backward kernel reads.
+__global__ __launch_bounds__(1024) void multibox_hnm_select_kernel(const long long* __restrict__ true_classes,
+                                                                   float* __restrict__ conf_all,
+                                                                   double* __restrict__ hnm_sum, int P, int ratio) {
+  __shared__ int hist[256];
+  __shared__ int s_i[4];       // 0: n_pos, 1: chosen bin, 2: remaining, 3: running tie rank
+  __shared__ int s_wave[16];
+  __shared__ double scratch[16];
+  const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const long long* tc = true_classes + (size_t)n * P;
+  float* v = conf_all + (size_t)n * P;
+  if (tid < 4) s_i[tid] = 0;
+  __syncthreads();
+  int np = 0;
+  for (int j = tid; j < P; j += 1024) np += tc[j] > 0;
+  for (int o = 32; o > 0; o >>= 1) np += __shfl_down(np, o);
+  if (lane == 0 && np) atomicAdd(&s_i[0], np);
+  __syncthreads();
+  const long long kk = (long long)ratio * s_i[0];
+  const int k = kk > P ? P : (int)kk;
+  if (k <= 0 || k >= P) {  // nothing / everything is kept
+    double acc = 0.0;
+    for (int j = tid; j < P; j += 1024) {
+      if (k > 0) acc += (double)v[j];
+      v[j] = k > 0 ? 1.f : 0.f;
+    }
+    const double t = msl::block_sum(acc, scratch);
+    if (tid == 0) hnm_sum[n] = t;
+    return;
+  }
+  unsigned prefix = 0;
+  if (tid == 0) s_i[2] = k;
+  for (int pass = 3; pass >= 0; --pass) {
+    const int shift = pass * 8;
+    for (int b = tid; b < 256; b += 1024) hist[b] = 0;
+    __syncthreads();
+    for (int j = tid; j < P; j += 1024) {
+      const unsigned key = sortable_key(v[j]);
+      if (pass == 3 || (key >> (shift + 8)) == (prefix >> (shift + 8))) atomicAdd(&hist[(key >> shift) & 255], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int remaining = s_i[2], cum = 0, b = 255;
+      for (; b > 0; --b) {
+        if (cum + hist[b] >= remaining) break;
+        cum += hist[b];
+      }
+      s_i[1] = b;
+      s_i[2] = remaining - cum;  // still needed from bin b
+    }
+    __syncthreads();
+    prefix |= (unsigned)s_i[1] << shift;
+  }
+  const unsigned tkey = prefix;
+  const int need = s_i[2];  // entries equal to T that are kept (>= 1)
+  double acc = 0.0;
+  for (int j0 = 0; j0 < P; j0 += 1024) {  // index order: the tie rank must count every earlier tie
+    const int j = j0 + tid;
+    const float val = j < P ? v[j] : 0.f;
+    const unsigned key = j < P ? sortable_key(val) : 0u;
+    const bool tie = j < P && key == tkey;
+    const unsigned long long bal = __ballot(tie);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) s_wave[wv] = __popcll(bal);
+    __syncthreads();
+    int off = s_i[3];
+    for (int w = 0; w < wv; ++w) off += s_wave[w];
+    const bool keep = j < P && (key > tkey || (tie && off + before < need));
+    if (keep) acc += (double)val;
+    if (j < P) v[j] = keep ? 1.f : 0.f;
+    __syncthreads();
+    if (tid == 0) {
+      int tot = 0;
+      for (int w = 0; w < 16; ++w) tot += s_wave[w];
+      s_i[3] += tot;
+    }
+    __syncthreads();
+  }
+  const double t = msl::block_sum(acc, scratch);
+  if (tid == 0) hnm_sum[n] = t;
+}
+
+// backward of the variants; every workgroup folds the forward partials (+ the per-image mined sums) itself and workgroup
+// 0 publishes loss_out = [conf, loc, n_positives], as multibox_loss_bwd_kernel<true> does.  write_grads = 0: losses only.
+__global__ __launch_bounds__(256) void multibox_loss_bwd_var_kernel(
+    const float* __restrict__ locs, const float* __restrict__ scores, const long long* __restrict__ true_classes,
+    const float* __restrict__ true_locs, float* __restrict__ loss_out, const double* __restrict__ partials, int nparts,
+    const double* __restrict__ hnm_sum, int nimages, const float* __restrict__ sel, const float* __restrict__ upstream,
+    float* __restrict__ dlocs, float* __restrict__ dscores, int total, int ncls, int flags, int write_grads) {
+  __shared__ float s_np;
+  const bool hnm = flags & VAR_HNM, smooth = flags & VAR_SMOOTH, focal = flags & VAR_FOCAL;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (threadIdx.x < 64) {
+    double ce = 0.0, l1 = 0.0, np = 0.0;
+    for (int k = threadIdx.x; k < nparts; k += 64) {
+      ce += partials[k * 3 + 0];
+      l1 += partials[k * 3 + 1];
+      np += partials[k * 3 + 2];
+    }
+    if (hnm)
+      for (int k = threadIdx.x; k < nimages; k += 64) ce += hnm_sum[k];
+    ce = msl::wave_sum(ce);
+    l1 = msl::wave_sum(l1);
+    np = msl::wave_sum(np);
+    if (threadIdx.x == 0) {
+      const float f = (float)np;
+      s_np = f;
+      if (blockIdx.x == 0) {
+        loss_out[0] = (float)ce / f;
+        loss_out[1] = (float)l1 / (f * 6.0f);
+        loss_out[2] = f;
+      }
+    }
+  }
+  __syncthreads();
+  const float npf = s_np;
+  if (i >= total || !write_grads) return;
+  const float gc = upstream[0] / npf, gl = upstream[1] / (npf * 6.0f);
+  const long long tc = true_classes[i];
+  const float* x = scores + (size_t)i * ncls;
+  float* ds = dscores + (size_t)i * ncls;
+  const bool active = tc > 0 || (tc == 0 && (!hnm || sel[i] != 0.f));
+  if (!active) {
+    for (int c = 0; c < ncls; ++c) ds[c] = 0.f;
+  } else if (focal) {
+    const float sgn = tc > 0 ? 1.f : -1.f;
+    const float z = sgn * x[1];
+    const float sp = fmaxf(-z, 0.f) + log1pf(expf(-fabsf(z)));
+    const float q = 1.f / (1.f + expf(z));
+    const float dz = -0.25f * q * q * (2.f * (1.f - q) * sp + q);
+    for (int c = 0; c < ncls; ++c) ds[c] = c == 1 ? gc * sgn * dz : 0.f;
+  } else {
+    float m = x[0];
+    for (int c = 1; c < ncls; ++c) m = fmaxf(m, x[c]);
+    float se = 0.f;
+    for (int c = 0; c < ncls; ++c) se += expf(x[c] - m);
+    for (int c = 0; c < ncls; ++c) {
+      const float sm = expf(x[c] - m) / se;
+      ds[c] = gc * (sm - (c == (int)tc ? 1.0f : 0.0f));
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 6; ++q) {
+    float g = 0.f;
+    if (tc > 0) {
+      const float d = locs[(size_t)i * 6 + q] - true_locs[(size_t)i * 6 + q];
+      if (smooth && fabsf(d) < 1.f) g = gl * d;
+      else g = d > 0.f ? gl : (d < 0.f ? -gl : 0.f);
+    }
+    dlocs[(size_t)i * 6 + q] = g;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -474,6 +709,38 @@ int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(multibox_loss_bwd_kernel<true>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores,
                      true_classes, true_locs, loss_out, workspace, LOSS_BLOCKS, upstream, dlocs, dscores, N * P, ncls);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// Optional loss variants (flags: 1 hard-negative mining with neg_pos_ratio, 2 smooth-L1, 4 focal; 0 = the live path).
+// var_ws: msl_multibox_loss_var_workspace_bytes(N, P) bytes = [N*P floats: mined mask][N doubles: mined sums].
+// dlocs / dscores may be null (forward only).  loss_out = [conf, loc, n_positives].
+size_t msl_multibox_loss_var_workspace_bytes(int N, int P) {
+  return (((size_t)N * P * sizeof(float) + 15) & ~(size_t)15) + (size_t)N * sizeof(double);
+}
+
+int msl_multibox_loss_var(const float* locs, const float* scores, const long long* true_classes, const float* true_locs,
+                          double* workspace, void* var_ws, float* loss_out, const float* upstream, float* dlocs,
+                          float* dscores, int* nan_flag, int N, int P, int ncls, int flags, int neg_pos_ratio,
+                          void* stream) {
+  if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC || flags < 0 || flags > 7 || neg_pos_ratio < 0) return MSL_ERR_ARG;
+  if ((flags & VAR_FOCAL) && ncls != 2) return MSL_ERR_UNSUPPORTED;  // defined for background + one class
+  if ((dlocs == nullptr) != (dscores == nullptr) || (dlocs && !upstream) || !var_ws) return MSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  float* sel = (float*)var_ws;
+  double* sums = (double*)((char*)var_ws + (((size_t)N * P * sizeof(float) + 15) & ~(size_t)15));
+  hipLaunchKernelGGL(multibox_loss_partial_var_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
+                     true_locs, workspace, sel, N * P, ncls, flags, nan_flag);
+  MSL_LAUNCH_CHECK();
+  if (flags & VAR_HNM) {
+    hipLaunchKernelGGL(multibox_hnm_select_kernel, dim3(N), dim3(1024), 0, st, true_classes, sel, sums, P, neg_pos_ratio);
+    MSL_LAUNCH_CHECK();
+  }
+  const int write = dlocs != nullptr;
+  hipLaunchKernelGGL(multibox_loss_bwd_var_kernel, dim3(write ? msl::cdiv(N * P, 256) : 1), dim3(256), 0, st, locs,
+                     scores, true_classes, true_locs, loss_out, workspace, LOSS_BLOCKS, sums, N, sel, upstream, dlocs,
+                     dscores, N * P, ncls, flags, write);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -209,9 +209,14 @@ class LSSD3D(nn.Module):
                  min_object_size=6,
                  max_object_size=14,
                  scales={},
-                 boxes_per_location=2
+                 boxes_per_location=2,
+                 *,
+                 hard_negative_mining=False,  # the three loss variants the reference keeps as commented code
+                 smooth_l1=False,             # (MultiBoxLoss docstring); default off = the reference's live loss
+                 focal_loss=False,
                  ):
         super(LSSD3D, self).__init__()
+        self._loss_variants = dict(hard_negative_mining=hard_negative_mining, smooth_l1=smooth_l1, focal=focal_loss)
         if aspect_ratios == {}:
             aspect_ratios = ASPECT_RATIOS
         self.hparams = dict(n_classes=n_classes, input_channels=input_channels, input_size=tuple(input_size),
@@ -221,6 +226,9 @@ class LSSD3D(nn.Module):
                             batch_size=batch_size, compute_metric_every_n_epochs=compute_metric_every_n_epochs,
                             comments=comments, aspect_ratios=aspect_ratios, min_object_size=min_object_size,
                             max_object_size=max_object_size, scales=scales, boxes_per_location=boxes_per_location)
+        # only non-default variants enter the hyper-parameters: default checkpoints keep the reference's key set
+        self.hparams.update({k: v for k, v in dict(hard_negative_mining=hard_negative_mining, smooth_l1=smooth_l1,
+                                                   focal_loss=focal_loss).items() if v})
         self.base_network_config = base_network_config
         self.cube = input_size[0] == input_size[1] == input_size[2]
         self.input_size = tuple(input_size)
@@ -270,7 +278,7 @@ class LSSD3D(nn.Module):
         # Prior boxes (ssd3d.py:244).  The draw below keeps RNG parity with the reference's third dummy pass.
         self.base.get_feature_map_infos(self.input_size, self.device)
         self.priors_cxcycz = self.create_prior_boxes(_draw=False) if torch.cuda.is_available() else None
-        self.loss_fn = MultiBoxLoss(self.priors_cxcycz, threshold=threshold, alpha=alpha)
+        self.loss_fn = MultiBoxLoss(self.priors_cxcycz, threshold=threshold, alpha=alpha, **self._loss_variants)
 
     # -- Lightning surface ------------------------------------------------------------------------------
     @property
@@ -586,22 +594,34 @@ class _MultiBoxLossFunction(torch.autograd.Function):
         st = ctx.st
         st["upstream"].copy_(torch.stack([g_conf.reshape(()), g_loc.reshape(())]))
         N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
-        _lib.call("msl_multibox_loss_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
-                  ptr(st["loss_out"]), ptr(st["upstream"]), ptr(st["dlocs"]), ptr(st["dscores"]), N, P, ncls, _stream())
+        lm = ctx.loss_mod
+        if lm.variant_flags:  # forward + backward of the variant in one call (the mined mask is rebuilt)
+            _lib.call("msl_multibox_loss_var", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
+                      ptr(st["ws"]), ptr(lm._var_ws(st, N, P)), ptr(st["loss_out"]), ptr(st["upstream"]), ptr(st["dlocs"]),
+                      ptr(st["dscores"]), None, N, P, ncls, lm.variant_flags, int(lm.neg_pos_ratio), _stream())
+        else:
+            _lib.call("msl_multibox_loss_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
+                      ptr(st["loss_out"]), ptr(st["upstream"]), ptr(st["dlocs"]), ptr(st["dscores"]), N, P, ncls, _stream())
         return None, st["dlocs"].clone(), st["dscores"].clone(), None, None, None, None
 
 
 class MultiBoxLoss(nn.Module):
     """The MultiBox loss (ssd3d.py:741-941): prior<->object matching + target encoding + confidence (cross
-    entropy over all non-ignored priors / number of positives) + localisation (mean |.| over positives) loss."""
+    entropy over all non-ignored priors / number of positives) + localisation (mean |.| over positives) loss.
 
-    def __init__(self, priors_cxcycz, threshold=0.5, neg_pos_ratio=3, alpha=1.):
+    ``hard_negative_mining`` / ``smooth_l1`` / ``focal`` (keyword-only, default off = the reference's live code) switch on
+    the variants the reference keeps as commented code: the mining recipe of ssd3d.py:926-932 with ``neg_pos_ratio``,
+    ``nn.SmoothL1Loss`` for the attribute it calls ``smooth_l1`` (ssd3d.py:758), MONAI's ``FocalLoss`` of ssd3d.py:760."""
+
+    def __init__(self, priors_cxcycz, threshold=0.5, neg_pos_ratio=3, alpha=1., *, hard_negative_mining=False,
+                 smooth_l1=False, focal=False):
         super(MultiBoxLoss, self).__init__()
         self.priors_cxcycz = priors_cxcycz
         self.priors_xyz = None
         self.threshold = threshold
         self.neg_pos_ratio = neg_pos_ratio
         self.alpha = alpha
+        self.variant_flags = (1 if hard_negative_mining else 0) | (2 if smooth_l1 else 0) | (4 if focal else 0)
         if type(self.threshold) == list:  # ssd3d.py:762-773
             if len(self.threshold) == 1:
                 self.thresholding_mode = "hard"
@@ -641,6 +661,14 @@ class MultiBoxLoss(nn.Module):
         return st
 
     @staticmethod
+    def _var_ws(st, N, P):
+        """Scratch of the loss variants (mined mask + per-image sums), allocated on first use."""
+        if "var_ws" not in st:
+            nbytes = _lib.load().msl_multibox_loss_var_workspace_bytes(N, P)
+            st["var_ws"] = torch.zeros((nbytes + 7) // 8, dtype=torch.float64, device=st["ws"].device)
+        return st["var_ws"]
+
+    @staticmethod
     def pack_targets(boxes, labels, dev):
         """list[(n_i,6)], list[(n_i,)] -> concatenated boxes (T,6) f32, labels (T,) i64, offsets (N+1,) i32, T."""
         sizes = [int(b.shape[0]) for b in boxes]
@@ -678,6 +706,15 @@ class MultiBoxLoss(nn.Module):
         sm = _stream()
         if not matched:
             self._run_match(st, N, gt_boxes, gt_labels, obj_off, T)
+        if self.variant_flags:
+            if int(self.neg_pos_ratio) != self.neg_pos_ratio or self.neg_pos_ratio < 0:
+                raise ValueError("neg_pos_ratio must be a non-negative integer")
+            up = with_backward_upstream
+            _lib.call("msl_multibox_loss_var", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
+                      ptr(st["ws"]), ptr(self._var_ws(st, N, P)), ptr(st["loss_out"]), ptr(up),
+                      ptr(st["dlocs"]) if up is not None else None, ptr(st["dscores"]) if up is not None else None,
+                      ptr(nan_flag), N, P, ncls, self.variant_flags, int(self.neg_pos_ratio), sm)
+            return
         if with_backward_upstream is not None:
             _lib.call("msl_multibox_loss_fwd_bwd", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]),
                       ptr(st["ws"]), ptr(st["loss_out"]), ptr(with_backward_upstream), ptr(st["dlocs"]), ptr(st["dscores"]),

@@ -74,22 +74,54 @@ def match_batch(boxes, labels, priors_c, threshold):
     return true_classes, true_locs, matched
 
 
-def multibox_loss(pred_locs, pred_scores, boxes, labels, priors_c, threshold):
+def focal_binary(logit_fg, is_pos, gamma=2.0, weight=0.25):
+    """The loss the reference names in its commented line ssd3d.py:760: MONAI ``FocalLoss(reduction="none", gamma=2,
+    to_onehot_y=True, include_background=False, weight=0.25)``.  With two classes and the background channel
+    excluded that is a sigmoid focal loss on the foreground logit alone:  weight * (1 - p_t)^gamma * BCE(x, t).
+    MONAI is not installed here and the reference holds no output of it: PARITY UNPINNED (published formula only)."""
+    t = is_pos.to(logit_fg.dtype)
+    bce = torch.nn.functional.binary_cross_entropy_with_logits(logit_fg, t, reduction="none")
+    invprobs = torch.nn.functional.logsigmoid(-logit_fg * (t * 2 - 1))  # log(1 - p_t)
+    return weight * (invprobs * gamma).exp() * bce
+
+
+def multibox_loss(pred_locs, pred_scores, boxes, labels, priors_c, threshold, hard_negative_mining=False,
+                  smooth_l1=False, focal=False, neg_pos_ratio=3):
     """-> (conf_loss, loc_loss) scalars.  ssd3d.py:890-941 live code path: plain L1 mean over
     positives x 6 (``nn.L1Loss``, ssd3d.py:758,896); cross entropy of every prior with ignored (-1)
     priors re-targeted to class 0 and then zeroed (ssd3d.py:913-917); all negatives + positives summed and
-    divided by the number of positives (ssd3d.py:924-933; hard-negative mining is commented out)."""
+    divided by the number of positives (ssd3d.py:924-933; hard-negative mining is commented out).
+
+    Optional variants (all off = the live path above):
+    ``hard_negative_mining``: the commented recipe ssd3d.py:926-932 - per image, only the ``neg_pos_ratio * n_positives``
+    largest entries of ``conf_loss_neg`` (positives zeroed) are summed; equal losses keep index order (stable sort).
+    ``smooth_l1``: ``nn.SmoothL1Loss()`` (beta 1, mean) in place of ``nn.L1Loss()`` (the attribute's name, ssd3d.py:758).
+    ``focal``: ``focal_binary`` in place of the cross entropy (two classes only)."""
     n, p, n_classes = pred_scores.shape
     assert p == priors_c.size(0) == pred_locs.size(1)
     true_classes, true_locs, _ = match_batch(boxes, labels, priors_c, threshold)
     positive = true_classes > 0
-    loc_loss = (pred_locs[positive] - true_locs[positive]).abs().mean()
-    target = true_classes.clamp(min=0).view(-1)
-    ce = torch.nn.functional.cross_entropy(pred_scores.reshape(-1, n_classes), target, reduction="none").view(n, p)
+    if smooth_l1:
+        loc_loss = torch.nn.functional.smooth_l1_loss(pred_locs[positive], true_locs[positive])
+    else:
+        loc_loss = (pred_locs[positive] - true_locs[positive]).abs().mean()
+    if focal:
+        assert n_classes == 2, "the focal variant is defined for background + one class"
+        ce = focal_binary(pred_scores[..., 1], positive)
+    else:
+        target = true_classes.clamp(min=0).view(-1)
+        ce = torch.nn.functional.cross_entropy(pred_scores.reshape(-1, n_classes), target, reduction="none").view(n, p)
     ce = torch.where(true_classes < 0, torch.zeros_like(ce), ce)
     neg = ce.clone()
     neg[positive] = 0.0
-    conf_loss = (neg.sum() + ce[positive].sum()) / positive.sum().float()
+    if hard_negative_mining:
+        n_hard = neg_pos_ratio * positive.sum(dim=1)  # (N)  ssd3d.py:907-908
+        neg_sorted, _ = neg.sort(dim=1, descending=True, stable=True)  # ssd3d.py:926
+        ranks = torch.arange(p).unsqueeze(0).expand_as(neg_sorted)  # ssd3d.py:927
+        hard = ranks < n_hard.unsqueeze(1)  # ssd3d.py:928
+        conf_loss = (neg_sorted[hard].sum() + ce[positive].sum()) / positive.sum().float()  # ssd3d.py:929,932
+    else:
+        conf_loss = (neg.sum() + ce[positive].sum()) / positive.sum().float()
     if torch.isnan(loc_loss):  # ssd3d.py:938-940 (empty-GT batch)
         raise Exception("Loss is NaN")
     return conf_loss, loc_loss

@@ -93,6 +93,74 @@ def test_matching_and_loss_golden(name):
     np.testing.assert_allclose(scores.grad.cpu().numpy().reshape(-1)[::17], g[f"{name}__dscores_s17"], rtol=RTOL, atol=1e-8)
 
 
+@pytest.mark.parametrize("hnm,smooth,focal", [(True, False, False), (False, True, False), (False, False, True),
+                                              (True, True, True), (True, True, False)])
+@pytest.mark.parametrize("name,ratio,ties", [("soft_random", 3, False), ("hard_float", 1, False), ("soft_random", 3, True),
+                                             ("soft_random", 10000, False), ("empty_image", 2, False),
+                                             ("many_230", 3, False)])
+def test_loss_variants_match_the_oracle(name, ratio, ties, hnm, smooth, focal):
+    """Hard-negative mining / smooth-L1 / focal (default off) against the oracle's restatement of the
+    reference's commented recipe: losses within 1e-4, gradients within 1e-4 of torch autograd on the oracle.  ``ties``:
+    many priors share one score vector, so the mined threshold falls inside a run of equal losses (index order decides)."""
+    from mslesions3d_amd.ssd3d import MultiBoxLoss
+    m = hip_model()
+    c = cases.matching_cases()[name]
+    n = len(c["boxes"])
+    loss_fn = MultiBoxLoss(m.priors_cxcycz, threshold=c["threshold"], neg_pos_ratio=ratio, alpha=1.0,
+                           hard_negative_mining=hnm, smooth_l1=smooth, focal=focal)
+    locs, scores = detinit.make_head_outputs(c["head_seed"], n, cases.P_C64)
+    locs = locs * 3.0  # residuals on both sides of the smooth-L1 knee
+    if ties:
+        scores = scores.clone()
+        scores[:, 100:900] = scores[:, 100:101]
+    boxes = [b.to(DEV) for b in c["boxes"]]
+    labels = [l.to(DEV) for l in c["labels"]]
+    gl, gs = locs.to(DEV).requires_grad_(True), scores.to(DEV).requires_grad_(True)
+    conf, loc = loss_fn(gl, gs, boxes, labels)
+    (conf + 0.5 * loc).backward()
+    ol, osc = locs.clone().requires_grad_(True), scores.clone().requires_grad_(True)
+    oc, olc = OMB.multibox_loss(ol, osc, c["boxes"], c["labels"], m.priors_cxcycz.cpu(), c["threshold"],
+                                hard_negative_mining=hnm, smooth_l1=smooth, focal=focal, neg_pos_ratio=ratio)
+    (oc + 0.5 * olc).backward()
+    np.testing.assert_allclose(conf.item(), oc.item(), rtol=1e-4)
+    np.testing.assert_allclose(loc.item(), olc.item(), rtol=1e-4)
+    np.testing.assert_allclose(gl.grad.cpu().numpy(), ol.grad.numpy(), rtol=1e-4, atol=1e-8)
+    np.testing.assert_allclose(gs.grad.cpu().numpy(), osc.grad.numpy(), rtol=1e-4, atol=1e-8)
+    # forward-only entry (no gradient buffers) publishes the same losses
+    with torch.no_grad():
+        c2, l2 = loss_fn(locs.to(DEV), scores.to(DEV), boxes, labels)
+    assert c2.item() == conf.item() and l2.item() == loc.item()
+
+
+def test_loss_variants_in_the_fused_training_step():
+    """The fused trainer with all three variants on: same losses as the autograd route through the same kernels."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    size = (64, 64, 64)
+    x = detinit.make_volume_batch(5, 2, 1, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, 2, size)
+    boxes, labels = [b.to(DEV) for b in boxes], [l.to(DEV) for l in labels]
+    kw = dict(threshold=[0.1, 0.2], hard_negative_mining=True, smooth_l1=True, focal_loss=True)
+    a, b = hip_model(1, size, **kw).train(), hip_model(1, size, **kw).train()
+    assert a.loss_fn.variant_flags == 7 and a.hparams["focal_loss"] is True
+    out = FusedTrainer(a).step(x, boxes, labels)
+    locs, scores = b(x)
+    conf, loc = b.loss_fn(locs, scores, boxes, labels)
+    np.testing.assert_allclose(out["conf"], conf.item(), rtol=1e-6)
+    np.testing.assert_allclose(out["loc"], loc.item(), rtol=1e-6)
+
+
+def test_focal_variant_needs_two_classes():
+    from mslesions3d_amd._lib import HipKernelError
+    from mslesions3d_amd.ssd3d import MultiBoxLoss
+    m = hip_model()
+    c = cases.matching_cases()["soft_random"]
+    loss_fn = MultiBoxLoss(m.priors_cxcycz, threshold=c["threshold"], focal=True)
+    locs, _ = detinit.make_head_outputs(c["head_seed"], len(c["boxes"]), cases.P_C64)
+    scores3 = torch.zeros(locs.shape[0], locs.shape[1], 3)
+    with pytest.raises(HipKernelError, match="unsupported"):
+        loss_fn(locs.to(DEV), scores3.to(DEV), [b.to(DEV) for b in c["boxes"]], [l.to(DEV) for l in c["labels"]])
+
+
 def test_empty_gt_batch_raises():
     m = hip_model()
     locs, scores = (t.to(DEV) for t in detinit.make_head_outputs(1, 2, cases.P_C64))
