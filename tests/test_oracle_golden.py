@@ -83,6 +83,49 @@ def test_matching_and_loss(name):
     np.testing.assert_allclose(scores.grad.numpy().reshape(-1)[::17], g[f"{name}__dscores_s17"], rtol=1e-5, atol=1e-9)
 
 
+@pytest.mark.parametrize("name", ["soft_random", "empty_image", "many_230"])
+def test_loss_variants_properties(name):
+    """The optional variants have no golden vector in the reference (commented code): pin the oracle's restatement by
+    the properties the recipe implies.  Mining with k >= all negatives is the live loss; the mined sum is the brute-force
+    sum of the k largest entries per image and grows with k; smooth-L1 = L1 - 0.5 above the knee and d^2/2 below."""
+    c = cases.matching_cases()[name]
+    pri = oracle_model().priors_cxcycz
+    locs, scores = detinit.make_head_outputs(c["head_seed"], len(c["boxes"]), cases.P_C64)
+    args = (c["boxes"], c["labels"], pri, c["threshold"])
+    conf, loc = OMB.multibox_loss(locs, scores, *args)
+    conf_all, _ = OMB.multibox_loss(locs, scores, *args, hard_negative_mining=True, neg_pos_ratio=10 ** 6)
+    tc, tl, _ = OMB.match_batch(c["boxes"], c["labels"], pri, c["threshold"])
+    if bool(((tc > 0).sum(dim=1) > 0).all()):  # an image without positives mines k = ratio * 0 = 0 negatives (ssd3d.py:908)
+        assert abs(conf_all.item() - conf.item()) <= 1e-5 * abs(conf.item())
+    else:
+        assert conf_all.item() < conf.item()
+    ce = torch.nn.functional.cross_entropy(scores.reshape(-1, 2), tc.clamp(min=0).view(-1), reduction="none").view(tc.shape)
+    prev = None
+    for ratio in (0, 1, 3, 7):
+        mined, _ = OMB.multibox_loss(locs, scores, *args, hard_negative_mining=True, neg_pos_ratio=ratio)
+        brute = ce[tc > 0].double().sum()
+        for i in range(tc.shape[0]):
+            neg = torch.where(tc[i] == 0, ce[i], torch.zeros_like(ce[i])).double()
+            k = min(ratio * int((tc[i] > 0).sum()), neg.numel())
+            brute = brute + neg.topk(k).values.sum()
+        brute = brute / float((tc > 0).sum())
+        assert abs(mined.item() - brute.item()) <= 1e-5 * abs(brute.item())
+        assert prev is None or mined.item() >= prev - 1e-6
+        prev = mined.item()
+    for scale in (0.05, 30.0):  # all residuals below / above the knee
+        d = (locs * scale)[tc > 0] - tl[tc > 0]
+        _, sl = OMB.multibox_loss(locs * scale, scores, *args, smooth_l1=True)
+        _, l1 = OMB.multibox_loss(locs * scale, scores, *args)
+        want = torch.where(d.abs() < 1, 0.5 * d * d, d.abs() - 0.5).mean()
+        assert abs(sl.item() - want.item()) <= 1e-6 * abs(want.item()) and sl.item() <= l1.item()
+    foc, _ = OMB.multibox_loss(locs, scores, *args, focal=True)
+    x, t = scores[..., 1].double(), (tc > 0).double()
+    p = torch.sigmoid(x)
+    pt = t * p + (1 - t) * (1 - p)
+    want = (0.25 * (1 - pt) ** 2 * -(pt.clamp_min(1e-300)).log())[tc >= 0].sum() / float((tc > 0).sum())
+    assert abs(foc.item() - want.item()) <= 1e-5 * abs(want.item())
+
+
 def test_empty_gt_batch_raises():
     pri = oracle_model().priors_cxcycz
     locs, scores = detinit.make_head_outputs(1, 2, cases.P_C64)
