@@ -141,6 +141,28 @@ def main():
         eng.start_profile({f"dw_fwd{i}" for i in range(1, 8)})
         run(20)
         dw_all = eng.stop_profile()
+    # ... and the same seven launches re-issued alone from the recorded launch program (the step's own buffers and
+    # arguments), 50 back to back per layer between one event pair: kernel + dependent dispatch, without the ~5 us an
+    # event pair adds around a single 5 us kernel.  Idempotent launches (they rewrite the same outputs and partials).
+    dw_alone = {}
+    progs = list(getattr(trainer, "_programs", {}).values())
+    if progs and not args.profile_all:
+        by_tag = {tag: (fn, a) for fn, a, tag in progs[-1]["prog"] if fn is not None and str(tag).startswith("dw_fwd")}
+        with torch.cuda.stream(trainer._stream):
+            for i in range(1, 8):
+                if f"dw_fwd{i}" not in by_tag:
+                    continue
+                fn, a = by_tag[f"dw_fwd{i}"]
+                for _ in range(5):
+                    fn(*a)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(50):
+                    fn(*a)
+                e1.record()
+                e1.synchronize()
+                dw_alone[i] = e0.elapsed_time(e1) / 50 * 1e3
+        torch.cuda.synchronize()
     # diagnostic: pure host cost of enqueueing one step (GPU idle, empty queues -> no back-pressure)
     t_enq = []
     for _ in range(5):
@@ -208,10 +230,22 @@ def main():
             lay_b = [4.0 * (args.batch * c * (vol(pl.dims[i]) + vol(pl.dims[i + 1])) + c * 27) for i, c in enumerate(chans)]
             lay_us = [1e3 * sum(dw_all[f"dw_fwd{i}"]) / len(dw_all[f"dw_fwd{i}"]) for i in range(1, 8)]
             tot_gbs = sum(lay_b) / (sum(lay_us) * 1e-6) / 1e9
-            out["roofline"]["depthwise_fwd_all_layers"] = {
-                "algorithmic_bytes": sum(lay_b), "sum_launch_us": round(sum(lay_us), 2), "achieved": round(tot_gbs, 1),
-                "frac": round(tot_gbs / HBM_PEAK_GBS, 4), "per_layer_us": [round(u, 2) for u in lay_us],
-                "note": "all seven depthwise forwards of one step, HIP events in situ, separate 20-step pass"}
+            agg = {"algorithmic_bytes": sum(lay_b),
+                   "in_step_event_pairs": {"sum_launch_us": round(sum(lay_us), 2), "achieved": round(tot_gbs, 1),
+                                           "frac": round(tot_gbs / HBM_PEAK_GBS, 4),
+                                           "per_layer_us": [round(u, 2) for u in lay_us]},
+                   "note": "SURVEY 8(d): all seven depthwise forwards, 222.7 MB / sum(t) / peak.  in_step_event_pairs: a HIP "
+                           "event pair around each of the seven launches inside the replayed step (20-step pass after "
+                           "the timed region; each pair adds ~5 us of event/dispatch overhead to a ~5 us kernel).  "
+                           "back_to_back: each launch re-issued 50x alone from the recorded program on the step's "
+                           "buffers, one event pair per layer (kernel + dependent dispatch).  rocprofv3 kernel "
+                           "durations of the step: profiles/"}
+            if len(dw_alone) == 7:
+                alone = [dw_alone[i] for i in range(1, 8)]
+                gbs = sum(lay_b) / (sum(alone) * 1e-6) / 1e9
+                agg["back_to_back"] = {"sum_launch_us": round(sum(alone), 2), "achieved": round(gbs, 1),
+                                       "frac": round(gbs / HBM_PEAK_GBS, 4), "per_layer_us": [round(u, 2) for u in alone]}
+            out["roofline"]["depthwise_fwd_all_layers"] = agg
         print(f"host enqueue {t_host / args.steps * 1e3:.3f} ms/step of {dt / args.steps * 1e3:.3f} ms/step wall; "
               f"one step into empty queues: {t_host1 * 1e3:.3f} ms", file=sys.stderr)
         if args.profile_all:
