@@ -36,6 +36,9 @@ def parse():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=25)  # ~10 s of CPU work
+    ap.add_argument("--no-aggregate", action="store_true",
+                    help="skip the two extra all-depthwise-layer passes after the timed region (rocprofv3 runs: keeps the "
+                         "kernel statistics those of the training step alone)")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch and print a table (stderr)")
     return ap.parse_args()
 
@@ -137,7 +140,7 @@ def main():
     # SURVEY 8(d)'s aggregate over ALL seven depthwise forwards, timed in situ in a short pass of its own (14 more
     # event records per step would perturb the timed region above): outside the timed region, not part of `value`
     dw_all = None
-    if not args.profile_all:
+    if not args.profile_all and not args.no_aggregate:
         eng.start_profile({f"dw_fwd{i}" for i in range(1, 8)})
         run(20)
         dw_all = eng.stop_profile()
@@ -146,7 +149,7 @@ def main():
     # event pair adds around a single 5 us kernel.  Idempotent launches (they rewrite the same outputs and partials).
     dw_alone = {}
     progs = list(getattr(trainer, "_programs", {}).values())
-    if progs and not args.profile_all:
+    if progs and not args.profile_all and not args.no_aggregate:
         by_tag = {tag: (fn, a) for fn, a, tag in progs[-1]["prog"] if fn is not None and str(tag).startswith("dw_fwd")}
         with torch.cuda.stream(trainer._stream):
             for i in range(1, 8):

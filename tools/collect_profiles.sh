@@ -11,10 +11,10 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 python bench.py > "$out/bench.json" 2> "$out/bench.err"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks --output-format csv -- python3 "$root/bench.py" --steps 40 --warmup 10 --no-cpu-baseline > "$out/ks.log" 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/ks -o ks --output-format csv -- python3 "$root/bench.py" --steps 40 --warmup 10 --no-cpu-baseline --no-aggregate > "$out/ks.log" 2>&1
 cp "$(find /tmp/ks -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python3 "$root/bench.py" --steps 6 --warmup 6 --no-cpu-baseline > "$out/pmc_$c.log" 2>&1
+  rocprofv3 --pmc $c --kernel-trace -d /tmp/pmc_$c -o p --output-format csv -- python3 "$root/bench.py" --steps 6 --warmup 6 --no-cpu-baseline --no-aggregate > "$out/pmc_$c.log" 2>&1
   cp "$(find /tmp/pmc_$c -name '*counter_collection.csv' | head -1)" "$out/pmc_$c.csv"
 done
 ls -la "$out"
