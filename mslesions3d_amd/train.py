@@ -45,6 +45,10 @@ def build_parser():
     p.add_argument('-es', '--early_stopping', type=int, default=1)
     p.add_argument('-cm', '--compute_metric_every_n_epochs', type=int, default=1)
     p.add_argument('-coms', '--comments', type=str, default="")
+    # not in the reference's CLI: the loss variants it keeps as commented code (MultiBoxLoss docstring); default off
+    p.add_argument('--hard_negative_mining', action='store_true')
+    p.add_argument('--smooth_l1', action='store_true')
+    p.add_argument('--focal_loss', action='store_true')
     return p
 
 
@@ -70,7 +74,9 @@ def example(args):
                        compute_metric_every_n_epochs=args.compute_metric_every_n_epochs, use_wandb=False,
                        aspect_ratios=aspect_ratios, scales=scales, alpha=args.alpha, threshold=threshold,
                        min_object_size=args.min_object_size, max_object_size=args.max_object_size,
-                       base_network_config=args.base_network_config, boxes_per_location=args.boxes_per_location)
+                       base_network_config=args.base_network_config, boxes_per_location=args.boxes_per_location,
+                       hard_negative_mining=args.hard_negative_mining, smooth_l1=args.smooth_l1,
+                       focal_loss=args.focal_loss)
     model.init()
     model = model.to("cuda")
     trainer = FusedTrainer(model)
