@@ -223,6 +223,7 @@ class Engine:
         self.fold_bn = False     # fold EVERY BatchNorm into its consumers (slower: big layers have thousands of partials)
         # default: fold only the BatchNorms with at most this many partials per channel (tuning knob: MSL_FOLD_NP_MAX)
         self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "32"))
+        self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", str(self.fold_np_max)))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
         self.side = {}
         self.arena = None
@@ -358,6 +359,10 @@ class Engine:
 
         fold_max = (1 << 30) if self.fold_bn else self.fold_np_max
         folds = lambda NP: training and NP <= fold_max  # is the BatchNorm with NP partials folded into its consumers?
+        # a depthwise output's only consumer is the pointwise GEMM of its block (one fold per wave, 32-64 channels wide):
+        # a threshold of its own (MSL_FOLD_NP_MAX_PW; block 1's depthwise emits 64 partials)
+        fold_max_pw = (1 << 30) if self.fold_bn else self.fold_np_max_pw
+        folds_z = lambda NP: training and NP <= fold_max_pw
         deferred = []
         bn_layers = []  # (bn module, vector buffer, partials, NP, element count) of every BatchNorm, in order
 
@@ -386,10 +391,10 @@ class Engine:
         self._k("stem_fwd", "msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]),
                 ptr(pl.part_y[0]) if training else None, N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         od, oh, ow = pl.dims[0]
-        def bn_done(bn, vec, part, NP, count, name):
+        def bn_done(bn, vec, part, NP, count, name, folded=None):
             if not training:
                 return  # done above, for all layers at once
-            if folds(NP):
+            if folds(NP) if folded is None else folded:
                 finalize_later(bn, vec, part, NP, count, name)
             else:
                 self._bn_fwd(bn, vec, part, NP, count, training, st)
@@ -412,8 +417,8 @@ class Engine:
                         ptr(blk.conv1.weight), ptr(pl.z[i]), ptr(pl.part_z[i]) if training else None, N, sp["cin"], pd, ph,
                         pw, s, 0, st)
             flush()
-            bn_done(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, f"stat_z{i}")
-            if folds(pl.np_z[i]):
+            bn_done(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, f"stat_z{i}", folded=folds_z(pl.np_z[i]))
+            if folds_z(pl.np_z[i]):
                 self._k(f"pw_fwd{i}", "msl_pwconv_fwd_fold", ptr(pl.z[i]), ptr(pl.part_z[i]), pl.np_z[i], float(N * S),
                         ptr(blk.bn1.weight), ptr(blk.bn1.bias), blk.bn1.eps, ptr(blk.conv2.weight), ptr(pl.y[i]),
                         ptr(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
