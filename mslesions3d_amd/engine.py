@@ -190,6 +190,11 @@ class Plan:
             # hold BatchNorm reduce partials that are consumed only after the weight gradients of the layer were enqueued)
             self.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
             self.partials_w = torch.empty_like(self.partials)
+            # second set: odd blocks' weight gradients may run on the heads stream beside the even blocks' (Engine.split_wgrad)
+            self.ws_b = torch.empty_like(self.ws)
+            self.partials_w_b = torch.empty_like(self.partials)
+            self.ws_c = torch.empty_like(self.ws)       # third set: MSL_WGRAD_SPLIT=2 (a stream of its own)
+            self.partials_w_c = torch.empty_like(self.partials)
             # fused stem backward (block 1 is a stride-2 depthwise layer fed by a 32-channel stem that is not a head
             # feature): its dL/d(stem activation) is never materialised (Engine.backward)
             self.fused_stem_np = -1
@@ -222,6 +227,10 @@ class Engine:
         # MI355X it costs each consumer what the launch saved (depthwise block 1: 40 -> 49 us) — off by default.
         self.fold_bn = False     # fold EVERY BatchNorm into its consumers (slower: big layers have thousands of partials)
         # default: fold only the BatchNorms with at most this many partials per channel (tuning knob: MSL_FOLD_NP_MAX)
+        # 0: every block's weight gradients on the wgrad stream; 1: odd blocks on the heads stream (idle once the head
+        # gradients are done); 2: three ways, the third on a stream of its own
+        self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
+        self.extra = {}
         self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "32"))
         self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", str(self.fold_np_max)))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
@@ -266,6 +275,12 @@ class Engine:
             pr = int(os.environ.get("MSL_SIDE_STREAM_PRIORITY", "0"))
             self.side[key] = (torch.cuda.Stream(device=device, priority=pr), torch.cuda.Stream(device=device, priority=pr))
         return self.side[key]
+
+    def extra_stream(self, device):
+        key = (device.type, device.index)
+        if key not in self.extra:
+            self.extra[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MSL_SIDE_STREAM_PRIORITY", "0")))
+        return self.extra[key]
 
     @staticmethod
     def _event(pl, name):
@@ -576,8 +591,9 @@ class Engine:
         if ms:
             sH, sW = self.side_streams(pl.locs.device)
             stH, stW = sH.cuda_stream, sW.cuda_stream
+            stX = self.extra_stream(pl.locs.device).cuda_stream if self.split_wgrad > 1 else stW
         else:
-            stH = stW = st
+            stH = stW = stX = st
         N = pl.N
         specs = self.layer_specs
         feats = m.base.features
@@ -605,11 +621,15 @@ class Engine:
                     self._fork(pl, f"bucket_w{stage}", stW, dst)
                     if join_heads:
                         self._fork(pl, f"bucket_h{stage}", stH, dst)
+                    if stX != stW:
+                        self._fork(pl, f"bucket_x{stage}", stX, dst)
                 on_bucket_ready.presynced = True
             elif ms:  # the exchange follows the main stream: bring the side streams' work in first
                 self._fork(pl, f"bucket_w{stage}", stW, st)
                 if join_heads:
                     self._fork(pl, f"bucket_h{stage}", stH, st)
+                if stX != stW:
+                    self._fork(pl, f"bucket_x{stage}", stX, st)
             self._hook(on_bucket_ready, stage)
 
         # heads: the last scale feeds the chain immediately (main stream); the earlier scales are only needed when
@@ -685,19 +705,22 @@ class Engine:
             def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red):
                 if os.environ.get("MSL_DEBUG_SKIP_WGRAD") == "1":  # timing experiment: results are wrong
                     return
+                # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there (own scratch)
+                sets = [(stW, pl.ws, pl.partials_w), (stH, pl.ws_b, pl.partials_w_b), (stX, pl.ws_c, pl.partials_w_c)]
+                sX, wsX, pwX = sets[i % (self.split_wgrad + 1)] if ms else sets[0]
                 if ms:  # one event per layer: both weight gradients start once dL/dz_i is final
-                    self._wait(stW, ev_dz)
+                    self._wait(sX, ev_dz)
                 self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
-                        ptr(pl.bn_z[i][1]), ptr(gv[name + ".conv2.weight"]), ptr(pl.ws), N, sp["cin"], sp["cout"], S, stW)
+                        ptr(pl.bn_z[i][1]), ptr(gv[name + ".conv2.weight"]), ptr(wsX), N, sp["cin"], sp["cout"], S, sX)
                 if fused_stem:
                     if ms:
-                        self._wait(stW, ev_red)
+                        self._wait(sX, ev_red)
                     self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_finalize", ptr(pl.partials_wf), pl.fused_stem_np,
-                            ptr(gv[name + ".conv1.weight"]), sp["cin"], stW)
+                            ptr(gv[name + ".conv1.weight"]), sp["cin"], sX)
                     return
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
-                        ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pl.partials_w),  # never pl.partials: it may hold the next BatchNorm's reduce partials
-                        N, sp["cin"], pd, ph, pw, s, stW)
+                        ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pwX),  # never pl.partials: it may hold the next BatchNorm's reduce partials
+                        N, sp["cin"], pd, ph, pw, s, sX)
 
             # issue what the previous layer left for the side streams, then queue this layer's
             for fn in pending:
@@ -709,7 +732,7 @@ class Engine:
                 for fn in pending:
                     fn()
                 pending = []
-            report(i)
+            report(i, join_heads=self.split_wgrad > 0)
         # stem
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
@@ -738,6 +761,8 @@ class Engine:
         if ms:  # every gradient is complete once the side streams have been joined
             self._fork(pl, "bwd_join_w", stW, st)
             self._fork(pl, "bwd_join_h", stH, st)
+            if stX != stW:
+                self._fork(pl, "bwd_join_x", stX, st)
         report(0)
 
     def check_nan(self, pl):
