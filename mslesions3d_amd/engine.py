@@ -231,6 +231,9 @@ class Engine:
         # gradients are done); 2: three ways, the third on a stream of its own
         self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
         self.extra = {}
+        self.early_pw_bww = os.environ.get("MSL_EARLY_PW_BWW", "0") == "1"
+        e = os.environ.get("MSL_WGRAD_ON_HEADS")
+        self.wgrad_on_heads = None if e is None else {int(v) for v in e.split(",") if v.strip()}
         self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "32"))
         self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", str(self.fold_np_max)))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
@@ -672,6 +675,8 @@ class Engine:
             # ~10 us kernels, so any launch queued in front of its next link shows up as idle time.
             self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st, pre_np=pre_np)
             pre_np = None
+            # dL/dy_i is final here: the pointwise weight gradient may start two or three chain kernels before dL/dz_i is
+            ev_dy = self._record(pl, f"dy{i}", st) if ms and self.early_pw_bww else None
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
                     sp["cout"], S, st)
             self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
@@ -702,16 +707,21 @@ class Engine:
             else:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
-            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red):
+            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red,
+                       ev_dy=ev_dy):
                 if os.environ.get("MSL_DEBUG_SKIP_WGRAD") == "1":  # timing experiment: results are wrong
                     return
                 # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there (own scratch)
                 sets = [(stW, pl.ws, pl.partials_w), (stH, pl.ws_b, pl.partials_w_b), (stX, pl.ws_c, pl.partials_w_c)]
                 sX, wsX, pwX = sets[i % (self.split_wgrad + 1)] if ms else sets[0]
-                if ms:  # one event per layer: both weight gradients start once dL/dz_i is final
-                    self._wait(sX, ev_dz)
+                if ms and self.wgrad_on_heads is not None:  # experiment knob: explicit list of blocks for the heads stream
+                    sX, wsX, pwX = sets[1] if i in self.wgrad_on_heads else sets[0]
+                if ms:  # the pointwise gradient needs dL/dy_i, the depthwise one dL/dz_i
+                    self._wait(sX, ev_dy if ev_dy is not None else ev_dz)
                 self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
                         ptr(pl.bn_z[i][1]), ptr(gv[name + ".conv2.weight"]), ptr(wsX), N, sp["cin"], sp["cout"], S, sX)
+                if ms and ev_dy is not None:
+                    self._wait(sX, ev_dz)
                 if fused_stem:
                     if ms:
                         self._wait(sX, ev_red)
