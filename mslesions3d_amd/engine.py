@@ -621,10 +621,11 @@ class Engine:
                 dst = comm.cuda_stream
                 self._fork(pl, f"bucket_m{stage}", st, dst)
                 if ms:
-                    self._fork(pl, f"bucket_w{stage}", stW, dst)
-                    if join_heads:
+                    if dst != stW:
+                        self._fork(pl, f"bucket_w{stage}", stW, dst)
+                    if join_heads and dst != stH:
                         self._fork(pl, f"bucket_h{stage}", stH, dst)
-                    if stX != stW:
+                    if stX != stW and dst != stX:
                         self._fork(pl, f"bucket_x{stage}", stX, dst)
                 on_bucket_ready.presynced = True
             elif ms:  # the exchange follows the main stream: bring the side streams' work in first

@@ -35,6 +35,15 @@ class FusedTrainer:
     def _reducer(self, arena):
         if self.reducer is None or self.reducer.arena is not arena:
             self.reducer = GradBucketReducer(arena, self.n_buckets, self.group)
+            # which stream carries the overlapped collectives (MSL_DP_COMM_STREAM=heads|wgrad|own).  A fifth HIP stream
+            # per process is not free on this runtime: in the one-rank rehearsal a stream of their own costs 3.9 % of the
+            # step, the wgrad stream 3.0 %, the heads stream 0.7 % (it is idle between the head gradients and the odd
+            # blocks' weight gradients, and a bucket has to wait for that stream's work anyway)
+            which = os.environ.get("MSL_DP_COMM_STREAM", "heads")
+            eng = self.model._engine
+            if self.reducer.comm_stream is not None and eng.multi_stream and which in ("heads", "wgrad"):
+                sH, sW = eng.side_streams(arena.grad.device)
+                self.reducer.comm_stream = sH if which == "heads" else sW
         return self.reducer
 
     def _eager_step(self, images, gt_boxes, gt_labels, obj_off, total_objects, red):
