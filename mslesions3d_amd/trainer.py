@@ -19,6 +19,10 @@ from .ssd3d import MultiBoxLoss
 
 
 class FusedTrainer:
+    _GRAPH_MSG = ("HIP-graph capture of the training step (opt-in, MSL_USE_GRAPH=1 / use_graph) is not supported by the "
+                  "present multi-stream schedule: the capture ends with hipErrorStreamCaptureUnjoined and leaves the "
+                  "streams unusable; unset it (native launch-program replay is the measured-faster default)")
+
     def __init__(self, model, lr=None, n_buckets=3, process_group=None):
         self.model = model
         self.opt = FusedAdam(model, lr=model.lr if lr is None else lr, weight_decay=0.0005)
@@ -117,12 +121,17 @@ class FusedTrainer:
                 pl.saved_input, pl.trained_mode = images, True
                 self.opt.prepare_step(grad_scale=1.0 / red.world)
                 graph_ok = self.use_graph and not red.active
+                parts = None
                 if eng.prof is not None and graph_ok:
                     # time the tagged launches individually, everything before / after them stays a captured graph
                     tags = frozenset(eng.prof_tags)
                     parts = entry.setdefault("segments", {}).get(tags)
                     if parts is None:
-                        parts = entry["segments"][tags] = _lib.capture_segments(prog, stream, tags)
+                        try:
+                            parts = entry["segments"][tags] = _lib.capture_segments(prog, stream, tags)
+                        except _lib.HipKernelError as e:
+                            raise _lib.HipKernelError(self._GRAPH_MSG) from e
+                if parts is not None:
                     _lib.run_segments(parts, stream, eng.prof, lambda: torch.cuda.Event(enable_timing=True))
                 elif eng.prof is not None:
                     tags = frozenset(eng.prof_tags)
@@ -135,17 +144,8 @@ class FusedTrainer:
                         try:
                             entry["graph"] = _lib.capture_graph(prog, stream)
                         except _lib.HipKernelError as e:
-                            # opt-in path (MSL_USE_GRAPH=1); the present schedule leaves a forked stream unjoined at the end
-                            # of the capture (hipErrorStreamCaptureUnjoined): say so and keep replaying natively
-                            import warnings
-                            warnings.warn(f"HIP-graph capture of the training step failed ({e}); using native replay")
-                            self.use_graph = False
-                    if entry["graph"] is not None:
-                        _lib.check(_lib.load().msl_graph_launch(entry["graph"], stream), "msl_graph_launch")
-                    else:
-                        if "native" not in entry:
-                            entry["native"] = _lib.compile_program(prog)
-                        _lib.replay_native(entry["native"])
+                            raise _lib.HipKernelError(self._GRAPH_MSG) from e
+                    _lib.check(_lib.load().msl_graph_launch(entry["graph"], stream), "msl_graph_launch")
                 else:
                     if "native" not in entry:
                         entry["native"] = _lib.compile_program(prog)
