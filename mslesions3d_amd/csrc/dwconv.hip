@@ -896,6 +896,240 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_ke
   }
 }
 
+// Weight gradient on the same register-marching layout (bwd-weight of the layers the two kernels above run forward):
+// dw[c][k] = sum over outputs of dy[o] * a[o*s - 1 + k].  The wave holds its input planes AND the dy planes of its
+// output slab in registers, every lane accumulates 27 tap sums over its cells, the lanes of a channel are then summed
+// (DPP / wave sums in fp64, fixed order) into partials [C*27][NP]; msl_dwconv_bwd_weight_finalize adds the NP partials.
+template <int P4>
+__device__ __forceinline__ double group_sum(double v, int lane) {  // sum over each aligned group of P4 lanes
+  if constexpr (P4 >= 64) {
+    return msl::wave_sum(v);
+  } else if constexpr (P4 == 32) {
+    v = msl::row16_sum(v);
+    const double lo = msl::lane_value(v, 0) + msl::lane_value(v, 16), hi = msl::lane_value(v, 32) + msl::lane_value(v, 48);
+    return lane < 32 ? lo : hi;
+  } else if constexpr (P4 == 16) {
+    return msl::row16_sum(v);
+  } else if constexpr (P4 == 8) {
+    v += msl::dpp_mov<0xB1>(v); v += msl::dpp_mov<0x4E>(v); v += msl::dpp_mov<0x141>(v);
+    return v;
+  } else {
+    static_assert(P4 == 4, "lane groups of 4, 8, 16, 32 or 64");
+    v += msl::dpp_mov<0xB1>(v); v += msl::dpp_mov<0x4E>(v);
+    return v;
+  }
+}
+
+template <int LOGW4, int LOGH, int SL>
+__global__ __launch_bounds__(256) void dw_s1_wave_bww_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ dy, double* __restrict__ partials, int C, int D, int nslabs, int Nbatch) {
+  constexpr int W4 = 1 << LOGW4, H = 1 << LOGH, P4 = W4 * H, CPW = 64 / P4, W = 4 * W4, HW = H * W, NPL = SL + 2;
+  const int lane = threadIdx.x & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int CG = C / CPW;
+  if (gw >= Nbatch * CG * nslabs) return;  // whole wave
+  const int slab = gw % nslabs, vg = gw / nslabs;
+  const int n = vg / CG, c0 = (vg % CG) * CPW;
+  const int cl = CPW == 1 ? 0 : lane >> (LOGW4 + LOGH);
+  const int h = (lane >> LOGW4) & (H - 1), w4 = lane & (W4 - 1);
+  const int c = c0 + cl;
+  const int od0 = slab * SL;
+
+  const size_t cell = (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
+  float4 pv[NPL], dv[SL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = min(max(od0 - 1 + i, 0), D - 1);
+    pv[i] = *reinterpret_cast<const float4*>(x + cell + (size_t)p * HW);
+  }
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    const int od = min(od0 + o, D - 1);
+    dv[o] = *reinterpret_cast<const float4*>(dy + cell + (size_t)od * HW);
+  }
+  const bool affine = in_scale != nullptr;
+  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) msl::pin(pv[i]);
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    msl::pin(dv[o]);
+    if (od0 + o >= D) dv[o] = make_float4(0.f, 0.f, 0.f, 0.f);  // wave-uniform (ragged last slab)
+  }
+
+  const bool up_ok = h > 0, dn_ok = h < H - 1, lf_ok = w4 > 0, rt_ok = w4 < W4 - 1;
+  float a27[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) a27[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = od0 - 1 + i;
+    if (p < 0 || p >= D) continue;  // wave-uniform
+    float4 m = pv[i];
+    if (affine) {
+      m.x = msl::act(m.x, sc, sh); m.y = msl::act(m.y, sc, sh);
+      m.z = msl::act(m.z, sc, sh); m.w = msl::act(m.w, sc, sh);
+    }
+    float R[3][6];
+    R[1][1] = m.x; R[1][2] = m.y; R[1][3] = m.z; R[1][4] = m.w;
+    {
+      const float a = lane_minus<W4>(m.x, lane), b = lane_minus<W4>(m.y, lane);
+      const float cc = lane_minus<W4>(m.z, lane), d = lane_minus<W4>(m.w, lane);
+      R[0][1] = up_ok ? a : 0.f; R[0][2] = up_ok ? b : 0.f; R[0][3] = up_ok ? cc : 0.f; R[0][4] = up_ok ? d : 0.f;
+    }
+    {
+      const float a = lane_plus<W4>(m.x, lane), b = lane_plus<W4>(m.y, lane);
+      const float cc = lane_plus<W4>(m.z, lane), d = lane_plus<W4>(m.w, lane);
+      R[2][1] = dn_ok ? a : 0.f; R[2][2] = dn_ok ? b : 0.f; R[2][3] = dn_ok ? cc : 0.f; R[2][4] = dn_ok ? d : 0.f;
+    }
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+      if constexpr (W4 > 1) {
+        const float l = lane_minus<1>(R[kh][4], lane), r = lane_plus<1>(R[kh][1], lane);
+        R[kh][0] = lf_ok ? l : 0.f;
+        R[kh][5] = rt_ok ? r : 0.f;
+      } else {
+        R[kh][0] = 0.f;
+        R[kh][5] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int o = i - kd;
+      if (o < 0 || o >= SL) continue;
+      const float4 d = dv[o];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          a27[kd * 9 + kh * 3 + kw] += fmaf(d.w, R[kh][kw + 3], fmaf(d.z, R[kh][kw + 2], fmaf(d.y, R[kh][kw + 1], d.x * R[kh][kw])));
+    }
+  }
+  const int NP = Nbatch * nslabs, pidx = n * nslabs + slab;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const double t = group_sum<P4>((double)a27[k], lane);
+    if ((lane & (P4 - 1)) == 0) partials[((size_t)c * 27 + k) * NP + pidx] = t;
+  }
+}
+
+template <int LOGW4, int LOGOH, int SL>
+__global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_bww_kernel(
+    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ dy, double* __restrict__ partials, int C, int D, int OD, int nslabs, int Nbatch) {
+  constexpr int W4 = 1 << LOGW4, OH = 1 << LOGOH, LOGC = LOGW4 + LOGOH, CELLS = 1 << LOGC;
+  constexpr int CPW = CELLS >= 64 ? 1 : 64 / CELLS, WPP = CELLS >= 64 ? CELLS / 64 : 1;
+  constexpr int W = 4 * W4, H = 2 * OH, HW = H * W, OW = 2 * W4, OHW = OH * OW, NPL = 2 * SL + 1;
+  constexpr int WPG = WPP == 1 ? 4 : (WPP < 4 ? WPP : 4), GPP = WPP == 1 ? 1 : WPP / WPG;
+  const int lane = threadIdx.x & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * WPG + (threadIdx.x >> 6));
+  const int CG = C / CPW;
+  if (WPP == 1 && gw >= Nbatch * CG * nslabs) return;  // whole wave (WPP > 1: the grid is exact)
+  const int part = gw % WPP, t0 = gw / WPP;
+  const int slab = t0 % nslabs, vg = t0 / nslabs;
+  const int n = vg / CG, c0 = (vg % CG) * CPW;
+  const int cl = CPW == 1 ? 0 : lane >> LOGC;
+  const int cell = CPW == 1 ? part * 64 + lane : lane & (CELLS - 1);
+  const int oh = cell >> LOGW4, w4 = cell & (W4 - 1);
+  const int c = c0 + cl;
+  const int od0 = slab * SL;
+  const bool up_ok = oh > 0, lf_ok = w4 > 0;
+
+  const float* xc = x + (size_t)(n * C + c) * D * HW + w4 * 4;
+  const int row_m = (up_ok ? 2 * oh - 1 : 0) * W, row_0 = 2 * oh * W;
+  float4 pv[NPL][3];
+  float2 dv[SL];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = min(max(2 * od0 - 1 + i, 0), D - 1);
+    const float* xp = xc + (size_t)p * HW;
+    pv[i][0] = *reinterpret_cast<const float4*>(xp + row_m);
+    pv[i][1] = *reinterpret_cast<const float4*>(xp + row_0);
+    pv[i][2] = *reinterpret_cast<const float4*>(xp + row_0 + W);
+  }
+  const float* dyc = dy + (size_t)(n * C + c) * OD * OHW + oh * OW + 2 * w4;
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    const int od = min(od0 + o, OD - 1);
+    dv[o] = *reinterpret_cast<const float2*>(dyc + (size_t)od * OHW);
+  }
+  const bool affine = in_scale != nullptr;
+  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) msl::pin(pv[i][r]);
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    asm volatile("" : "+v"(dv[o].x), "+v"(dv[o].y));
+    if (od0 + o >= OD) dv[o] = make_float2(0.f, 0.f);  // wave-uniform (ragged last slab)
+  }
+
+  float a27[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) a27[k] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = 2 * od0 - 1 + i;
+    if (p < 0 || p >= D) continue;  // wave-uniform
+    float T[3][5];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float4 m = pv[i][r];
+      if (affine) {
+        m.x = msl::act(m.x, sc, sh); m.y = msl::act(m.y, sc, sh);
+        m.z = msl::act(m.z, sc, sh); m.w = msl::act(m.w, sc, sh);
+      }
+      if (r == 0) {
+        m.x = up_ok ? m.x : 0.f; m.y = up_ok ? m.y : 0.f; m.z = up_ok ? m.z : 0.f; m.w = up_ok ? m.w : 0.f;
+      }
+      T[r][1] = m.x; T[r][2] = m.y; T[r][3] = m.z; T[r][4] = m.w;
+      if constexpr (W4 > 1) {
+        const float l = lane_minus<1>(m.w, lane);
+        T[r][0] = lf_ok ? l : 0.f;
+      } else {
+        T[r][0] = 0.f;
+      }
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      if ((i - kd) % 2 != 0 || i - kd < 0) continue;
+      const int o = (i - kd) / 2;
+      if (o >= SL) continue;
+      const float2 d = dv[o];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) a27[kd * 9 + kh * 3 + kw] += fmaf(d.y, T[kh][kw + 2], d.x * T[kh][kw]);
+    }
+  }
+  if constexpr (WPP > 1) {
+    __shared__ double red[27][WPG];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const double t = msl::wave_sum((double)a27[k]);
+      if (lane == 0) red[k][part % WPG] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 27) {
+      double t = 0.0;
+#pragma unroll
+      for (int q = 0; q < WPG; ++q) t += red[threadIdx.x][q];
+      const int NP = Nbatch * nslabs * GPP, pidx = (n * nslabs + slab) * GPP + part / WPG;
+      partials[((size_t)c * 27 + threadIdx.x) * NP + pidx] = t;
+    }
+  } else {
+    constexpr int GRP = CELLS >= 64 ? 64 : CELLS;
+    const int NP = Nbatch * nslabs, pidx = n * nslabs + slab;
+#pragma unroll
+    for (int k = 0; k < 27; ++k) {
+      const double t = group_sum<GRP>((double)a27[k], lane);
+      if ((lane & (GRP - 1)) == 0) partials[((size_t)c * 27 + k) * NP + pidx] = t;
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Generic fallback (any W, any plane size): one output per thread straight from global memory.
 __global__ __launch_bounds__(256) void dw_fwd_naive_kernel(
@@ -1130,6 +1364,54 @@ void launch_wave_s2(const WavePlan& wp, const float* x, const float* in_scale, c
 #undef MSL_DW_WAVE2_SL
 }
 
+// weight gradient on the wave kernels (MSL_DW_WAVE_BWW=0 sends it back to the LDS-tiled / generic kernels)
+bool wave_bww_enabled() {
+  static const int on = getenv("MSL_DW_WAVE_BWW") ? atoi(getenv("MSL_DW_WAVE_BWW")) : 1;
+  return on != 0;
+}
+
+int wave_bww_num_partials(const WavePlan& wp, int N) { return N * wp.nslabs * (wp.wpp > 4 ? wp.wpp / 4 : 1); }
+
+void launch_wave_bww(const WavePlan& wp, int stride, const float* x, const float* in_scale, const float* in_shift,
+                     const float* dy, double* partials, int N, int C, int D, hipStream_t st) {
+  const int waves = N * (C / wp.cpw) * wp.nslabs * wp.wpp;
+  if (stride == 1) {
+    const dim3 grid(msl::cdiv(waves, 4)), block(256);
+#define MSL_DW_WAVE_BWW1(LW_, LH_)                                                                                \
+  switch (wp.SL) {                                                                                                \
+    case 8: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 8>), grid, block, 0, st, x, in_scale, in_shift,   \
+                               dy, partials, C, D, wp.nslabs, N); break;                                          \
+    case 4: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift,   \
+                               dy, partials, C, D, wp.nslabs, N); break;                                          \
+    case 2: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift,   \
+                               dy, partials, C, D, wp.nslabs, N); break;                                          \
+    default: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift,  \
+                                dy, partials, C, D, wp.nslabs, N); break;                                         \
+  }
+    if (wp.logw4 == 0) { MSL_DW_WAVE_BWW1(0, 2) }
+    else if (wp.logw4 == 1) { MSL_DW_WAVE_BWW1(1, 3) }
+    else { MSL_DW_WAVE_BWW1(2, 4) }
+#undef MSL_DW_WAVE_BWW1
+    return;
+  }
+  const int wpg = wp.wpp > 1 ? std::min(wp.wpp, 4) : 4, OD = (D - 1) / 2 + 1;
+  const dim3 grid(msl::cdiv(waves, wpg)), block(64 * wpg);
+#define MSL_DW_WAVE_BWW2(LW_, LH_)                                                                                \
+  switch (wp.SL) {                                                                                                \
+    case 4: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift,   \
+                               dy, partials, C, D, OD, wp.nslabs, N); break;                                      \
+    case 2: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift,   \
+                               dy, partials, C, D, OD, wp.nslabs, N); break;                                      \
+    default: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift,  \
+                                dy, partials, C, D, OD, wp.nslabs, N); break;                                     \
+  }
+  if (wp.logw4 == 1) { MSL_DW_WAVE_BWW2(1, 2) }
+  else if (wp.logw4 == 2) { MSL_DW_WAVE_BWW2(2, 3) }
+  else if (wp.logw4 == 3) { MSL_DW_WAVE_BWW2(3, 4) }
+  else { MSL_DW_WAVE_BWW2(4, 5) }
+#undef MSL_DW_WAVE_BWW2
+}
+
 template <typename K>
 int set_lds(K kernel, size_t bytes) {
   if (bytes > 64 * 1024) {
@@ -1163,6 +1445,15 @@ static const msl::BnFold nofold{nullptr, 0, 0, 1.0, nullptr, nullptr, 0.f};
 int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in_scale, const float* in_shift,
                                 double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
+  if (wave_bww_enabled()) {
+    const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+    if (wp.ok) {
+      launch_wave_bww(wp, stride, x, in_scale, in_shift, dy, partials, N, C, D, (hipStream_t)stream);
+      MSL_LAUNCH_CHECK();
+      return MSL_OK;
+    }
+  }
   DwPlan pl = make_plan(N, C, D, H, W, stride);
   // many channels per workgroup (tiny tail volumes): the per-channel epilogue reduction dominates and the
   // barrier-free wave-per-item kernel of dwconv_bwd.hip is faster
@@ -1205,6 +1496,10 @@ int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in
 }
 
 int msl_dwconv_bwd_weight_tiled_num_partials(int N, int C, int D, int H, int W, int stride) {
+  if (wave_bww_enabled()) {
+    const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+    if (wp.ok) return wave_bww_num_partials(wp, N);
+  }
   DwPlan pl = make_plan(N, C, D, H, W, stride);
   return (pl.variant == 0 || pl.G > 4) ? -1 : pl.num_partials;
 }

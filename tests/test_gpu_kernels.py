@@ -175,7 +175,10 @@ def test_dw_fwd_fold_matches_explicit_affine(N, C, dims, in_np, stride):
                                               (1, 4, (10, 40, 40), 2), (1, 3, (9, 40, 48), 1), (1, 2, (7, 96, 96), 2),
                                               (2, 64, (8, 8, 8), 2), (2, 64, (4, 4, 4), 1), (2, 16, (32, 32, 32), 2),
                                               (1, 8, (5, 8, 8), 1), (2, 8, (16, 16, 16), 1), (1, 4, (6, 12, 16), 1),
-                                              (2, 16, (32, 16, 32), 2), (1, 8, (20, 8, 8), 1)])
+                                              (2, 16, (32, 16, 32), 2), (1, 8, (20, 8, 8), 1),
+                                              # weight gradient on the wave kernels: split planes, odd depth, one plane
+                                              (1, 2, (6, 64, 64), 2), (1, 4, (7, 16, 16), 2), (3, 8, (2, 8, 8), 2),
+                                              (1, 2, (1, 16, 16), 1), (2, 16, (9, 4, 4), 1), (1, 2, (18, 32, 32), 2)])
 def test_dw_bwd(N, C, dims, stride):
     L = _lib.load()
     x = rnd(N, C, *dims, seed=4)
