@@ -563,6 +563,15 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
 #pragma unroll
   for (int i = 0; i < NSUB; ++i) acc[i] = (f32x16){0};
 
+  // the BatchNorm affine of this thread's activation rows: loaded once, not once per chunk (inside the chunk loop the
+  // compiler serialised them behind the tile loads: four extra memory round trips per 64-position chunk)
+  float scv[BNN / 16], shv[BNN / 16];
+#pragma unroll
+  for (int j = 0; j < BNN / 16; ++j) {
+    scv[j] = AFFINE ? in_scale[n0 + (tid >> 4) + j * 16] : 1.f;
+    shv[j] = AFFINE ? in_shift[n0 + (tid >> 4) + j * 16] : 0.f;
+  }
+
   for (int ch = ch_lo; ch < ch_hi; ++ch) {
     const int n = ch / chunks_per_img, s0 = (ch % chunks_per_img) * PC;
     const float* dyn = dY + ((size_t)n * Cout + m0) * S;
@@ -586,7 +595,7 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
       const int r = (tid >> 4) + i * 16, c4 = (tid & 15) * 4, col = s0 + c4;
       float4 v = st[i];
       if (AFFINE && r >= 64) {  // uniform per i: 64 % 16 == 0
-        const float sc = in_scale[n0 + r - 64], sh = in_shift[n0 + r - 64];
+        const float sc = scv[i >= 4 ? i - 4 : 0], sh = shv[i >= 4 ? i - 4 : 0];
         v.x = col < S ? msl::act(v.x, sc, sh) : 0.f;
         v.y = col + 1 < S ? msl::act(v.y, sc, sh) : 0.f;
         v.z = col + 2 < S ? msl::act(v.z, sc, sh) : 0.f;
