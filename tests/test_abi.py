@@ -67,6 +67,15 @@ def test_pure_host_entry_points():
     assert lib.msl_pwconv_fwd_num_partials(4, 32, 64, 32768) == 4 * 128   # two 32-column tiles per wave
     assert lib.msl_pwconv_fwd_num_partials(4, 512, 512, 64) == 4 * 2      # K-split wave form: 32-column tiles
     assert lib.msl_head_packed_weight_elems(128, 2) == 128 // 4 * 27 * 64
+    # statistic / weight-gradient partial counts of the depthwise wave kernels (config A): N x depth slabs (x workgroups
+    # of a split plane)
+    assert lib.msl_dwconv_fwd_num_partials(4, 32, 64, 64, 64, 2) == 4 * 8 * 2    # block 1: 8 slabs, two 4-wave workgroups
+    assert lib.msl_dwconv_fwd_num_partials(4, 64, 32, 32, 32, 2) == 4 * 4        # block 2: one 2-wave workgroup per plane
+    assert lib.msl_dwconv_fwd_num_partials(4, 128, 16, 16, 16, 1) == 4 * 2
+    assert lib.msl_dwconv_fwd_num_partials(4, 512, 4, 4, 4, 1) == 4 * 2
+    assert lib.msl_dwconv_bwd_weight_num_partials(4, 64, 32, 32, 32, 2) == 4 * 4
+    assert lib.msl_dwconv_bwd_weight_num_partials(4, 256, 8, 8, 8, 1) == 4 * 2
+    assert lib.msl_multibox_loss_var_workspace_bytes(4, 9344) == 4 * 9344 * 4 + 4 * 8
 
 
 def test_native_program_runner_covers_the_abi():
