@@ -87,11 +87,9 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
     if world > 1 or rehearse:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+        from mslesions3d_amd.parallel import init_distributed
+        # finite collective timeout + watchdog tear-down (see init_distributed): a lost rank ends the run with an error
+        init_distributed(backend, rank=rank, world_size=world, device=torch.device("cuda", local) if backend == "nccl" else None)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
@@ -119,7 +117,7 @@ def main():
     def run(nsteps):
         for s in range(nsteps):
             x, gb, gl, off, T = pool[s % len(pool)]
-            trainer.step_packed(x, gb, gl, off, T, sync=False)
+            trainer.step_packed(x, gb, gl, off, T, sync=False, resident=True)
 
     run(args.warmup)
     torch.cuda.synchronize()

@@ -17,7 +17,7 @@ import torch
 from scipy.ndimage import label as cc_label
 from torch.utils.data import DataLoader, Dataset
 
-from .synth import make_case
+from .synth import generate_volume, make_case  # noqa: F401
 
 
 def generate_artificial_dataset(output_dir, dataset_name, num_images=20, image_size=(64, 64, 64), num_objects=(1, 5),
@@ -27,18 +27,7 @@ def generate_artificial_dataset(output_dir, dataset_name, num_images=20, image_s
     os.makedirs(pjoin(root, "images"), exist_ok=True)
     os.makedirs(pjoin(root, "labels"), exist_ok=True)
     for idx in range(num_images):
-        np.random.seed(random_seed + idx)
-        data = np.random.rand(*image_size)
-        mask = np.zeros(image_size)
-        n = np.random.randint(*num_objects)
-        for _ in range(n + 1):
-            size = np.random.randint(object_size[0], object_size[1])
-            np.random.randint(0, 1)
-            tl = [np.random.randint(0, image_size[i] - size) for i in range(3)]
-            sl = tuple(slice(t, t + size) for t in tl)
-            data[sl] = data[sl] + 0.4
-            data = data.clip(0, 1)
-            mask[sl] = 1
+        data, mask, _ = generate_volume(idx, image_size, num_objects, object_size, random_seed)
         np.save(pjoin(root, "images", f"sub-{str(idx).zfill(4)}_image.npy"), data.astype(np.float32))
         np.save(pjoin(root, "labels", f"sub-{str(idx).zfill(4)}_seg.npy"), mask.astype(np.uint8))
     return root
@@ -65,6 +54,76 @@ def boxes_from_segmentation(seg, n_classes=1):
     return boxes, labels
 
 
+# ---- augmentations (reference train.py:132-145 -> datasets.py:99-122 registry; train pipeline only) -----------------
+# The reference applies MONAI's RandFlipd / RandRotate90d / RandAffined to the (image, segmentation) pair BEFORE the boxes
+# are extracted, so boxes always follow from the transformed mask.  Same here, on numpy arrays with a channel axis in
+# front.  flip / rotate90 are index permutations (exact; MONAI calls the same flip / rot90).  translate / scale are the
+# two RandAffined uses: resampling with bilinear (image) / nearest (mask) interpolation and reflection padding.  MONAI is
+# absent, so its random-number stream and its affine grid convention are NOT pinned (documented in DESIGN.md); the
+# transforms are drawn from ``np.random.RandomState(seed)``.
+
+def _aug_flip(img, seg, rs, spatial_axis=(0, 1, 2), prob=0.1):
+    if rs.rand() >= prob:
+        return img, seg
+    ax = tuple(a + 1 for a in ((spatial_axis,) if np.isscalar(spatial_axis) else spatial_axis))
+    return np.flip(img, ax), np.flip(seg, ax)
+
+
+def _aug_rotate90(img, seg, rs, spatial_axes=(0, 1), prob=0.1, max_k=3):
+    if rs.rand() >= prob:
+        return img, seg
+    k = int(rs.randint(max_k)) + 1
+    ax = tuple(a + 1 for a in spatial_axes)
+    return np.rot90(img, k, ax), np.rot90(seg, k, ax)
+
+
+def _rand_range(rs, rng, n=3):
+    """MONAI's per-axis parameter draw: a (lo, hi) pair draws uniform(lo, hi), a number f draws uniform(-f, f);
+    axes beyond the given entries get 0."""
+    out = []
+    for f in tuple(rng)[:n]:
+        out.append(rs.uniform(f[0], f[1]) if isinstance(f, (tuple, list)) else rs.uniform(-f, f))
+    return out + [0.0] * (n - len(out))
+
+
+def _aug_affine(img, seg, rs, mode=("bilinear", "nearest"), translate_range=None, scale_range=None,
+                padding_mode="reflection", prob=0.1):
+    from scipy.ndimage import affine_transform
+    if rs.rand() >= prob:
+        return img, seg
+    shift = _rand_range(rs, translate_range) if translate_range is not None else [0.0] * 3
+    zoom = [1.0 + v for v in _rand_range(rs, scale_range)] if scale_range is not None else [1.0] * 3
+    pad = {"reflection": "reflect", "border": "nearest", "zeros": "constant"}[padding_mode]
+    centre = (np.array(img.shape[1:], dtype=np.float64) - 1) / 2
+    mat = np.diag(zoom)
+    off = centre - mat @ centre + np.array(shift, dtype=np.float64)  # output voxel o samples input voxel M o + off
+    outs = []
+    for a, m in ((img, mode[0]), (seg, mode[1])):
+        order = 1 if m == "bilinear" else 0
+        outs.append(np.stack([affine_transform(c.astype(np.float32), mat, offset=off, order=order, mode=pad) for c in a]).astype(a.dtype))
+    return outs[0], outs[1]
+
+
+AUGMENTATIONS = {"flip": _aug_flip, "rotate90": _aug_rotate90, "affine": _aug_affine}
+
+# train.py:132-143: the names the CLI accepts and the parameters the reference binds to them
+REFERENCE_AUGMENTATIONS = [("flip", {"spatial_axis": (0, 1, 2), "prob": .5}),
+                           ("rotate90", {"spatial_axes": (1, 2), "prob": .5}),
+                           ("rotate90", {"spatial_axes": (0, 1), "prob": .5}),
+                           ("rotate90", {"spatial_axes": (0, 2), "prob": .5}),
+                           ("translate", {"mode": ("bilinear", "nearest"), "translate_range": (-3, 3), "prob": .7}),
+                           ("scale", {"mode": ("bilinear", "nearest"), "scale_range": (0.15, 0.15, 0.15),
+                                      "padding_mode": "reflection", "prob": .7})]
+
+
+def select_augmentations(names):
+    """train.py:145: keep the reference's entries whose name was asked for; translate / scale both become 'affine'."""
+    unknown = set(names) - {n for n, _ in REFERENCE_AUGMENTATIONS}
+    if unknown:
+        raise ValueError(f"unknown augmentation(s) {sorted(unknown)}; known: flip rotate90 translate scale")
+    return [(n.replace("translate", "affine").replace("scale", "affine"), kw) for n, kw in REFERENCE_AUGMENTATIONS if n in names]
+
+
 def _load(path_noext):
     if os.path.exists(path_noext + ".npy"):
         return np.load(path_noext + ".npy")
@@ -73,8 +132,13 @@ def _load(path_noext):
 
 
 class _Cases(Dataset):
-    def __init__(self, root, subjects, n_classes):
+    def __init__(self, root, subjects, n_classes, augmentations=None, seed=0):
         self.root, self.subjects, self.n_classes = root, subjects, n_classes
+        self.augmentations = list(augmentations or [])
+        for t in self.augmentations:
+            if (t if isinstance(t, str) else t[0]) not in AUGMENTATIONS:
+                raise ValueError(f"unknown transform {t!r}")
+        self.rs = np.random.RandomState(seed)
 
     def __len__(self):
         return len(self.subjects)
@@ -87,8 +151,13 @@ class _Cases(Dataset):
         if nz.any():
             std = img[nz].std()
             img[nz] = (img[nz] - img[nz].mean()) / (std if std != 0 else 1.0)
+        img, seg = img[None], np.asarray(seg)[None]  # add_channel
+        for t in self.augmentations:  # between normalizeintensity and bounding_boxes_generator (datasets.py:417-430)
+            name, kw = (t, {}) if isinstance(t, str) else t
+            img, seg = AUGMENTATIONS[name](img, seg, self.rs, **kw)
+        img = np.ascontiguousarray(img)
         boxes, labels = boxes_from_segmentation(seg, self.n_classes)
-        return {"img": torch.from_numpy(img[None]), "boxes": boxes, "labels": labels, "seg": [boxes, labels], "subject": s,
+        return {"img": torch.from_numpy(img), "boxes": boxes, "labels": labels, "seg": [boxes, labels], "subject": s,
                 "img_meta_dict": {"affine": np.eye(4)}, "seg_meta_dict": {}, "img_transforms": [], "seg_transforms": []}
 
 
@@ -115,6 +184,7 @@ class ExampleDataset:
         self.data_dir = d if dataset_name is None else pjoin(d, dataset_name)
         self.batch_size, self.num_workers, self.random_state = batch_size, num_workers, random_state
         self.n_classes, self.subject, self.percentage = n_classes, subject, percentage
+        self.augmentations = augmentations
         subs = sorted(s.replace("sub-", "")[:4] for s in os.listdir(pjoin(self.data_dir, "images")) if "sub-" in s)
         self.subjects_list = subs[:int(percentage * len(subs))] if percentage > 0 else subs
         self.train_dataset = self.test_dataset = self.predict_dataset = None
@@ -125,7 +195,7 @@ class ExampleDataset:
             train, test = [self.subject], [self.subject]
         else:
             train, test = train_test_split(self.subjects_list, test_size=0.2, random_state=self.random_state)
-        self.train_dataset = _Cases(self.data_dir, train, self.n_classes)
+        self.train_dataset = _Cases(self.data_dir, train, self.n_classes, self.augmentations, self.random_state)
         self.test_dataset = _Cases(self.data_dir, test, self.n_classes)
         self.predict_dataset = _Cases(self.data_dir, train if stage == "predict_train" else test, self.n_classes)
 

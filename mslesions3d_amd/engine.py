@@ -575,7 +575,7 @@ class Engine:
             self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), pl.N, C, D, H, W, ncls, st)
             if data_done_event is not None:  # the activation-gradient chain only waits for the data gradient
                 _lib.call("msl_event_record", data_done_event, st, tag="event")
-        if not weight or os.environ.get("MSL_DEBUG_SKIP_WGRAD") == "1":
+        if not weight:
             return
         self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
                 ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
@@ -710,8 +710,6 @@ class Engine:
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
             def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red,
                        ev_dy=ev_dy):
-                if os.environ.get("MSL_DEBUG_SKIP_WGRAD") == "1":  # timing experiment: results are wrong
-                    return
                 # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there (own scratch)
                 sets = [(stW, pl.ws, pl.partials_w), (stH, pl.ws_b, pl.partials_w_b), (stX, pl.ws_c, pl.partials_w_c)]
                 sX, wsX, pwX = sets[i % (self.split_wgrad + 1)] if ms else sets[0]

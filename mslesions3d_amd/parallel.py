@@ -15,6 +15,28 @@ import torch
 import torch.distributed as dist
 
 
+def init_distributed(backend="nccl", rank=None, world_size=None, device=None, timeout_s=None):
+    """One process per GPU: join the job's process group (``nccl`` = RCCL over xGMI on ROCm).
+
+    Failure handling: a collective that a peer never joins must not hang the job forever.  The group
+    gets a finite timeout (``MSL_DP_TIMEOUT_S``, default 180 s; torch's NCCL default is 10 min) and torch's watchdog is left
+    in its tear-down mode (``TORCH_NCCL_ASYNC_ERROR_HANDLING=1``): on a timeout or an RCCL error the watchdog aborts the
+    communicator and the process exits with the error instead of blocking in a stream wait.  No elasticity: the launcher
+    restarts the job from the last checkpoint (train.py --checkpoint restores optimiser, scheduler and epoch)."""
+    import datetime
+    rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if world_size is None else world_size
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "1")
+    timeout = datetime.timedelta(seconds=float(os.environ.get("MSL_DP_TIMEOUT_S", "180") if timeout_s is None else timeout_s))
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = device
+    dist.init_process_group(backend, rank=rank, world_size=world_size, timeout=timeout, **kw)
+    return dist.group.WORLD
+
+
 class GradBucketReducer:
     def __init__(self, arena, n_buckets=3, process_group=None):
         self.arena = arena

@@ -32,22 +32,27 @@ def build_parser():
 
 
 def save_predictions(subject, img_shape, boxes, labels, scores, min_score, output_dir):
-    """predict.py:155-232 without the NIfTI overlay."""
+    """predict.py:155-232 without the NIfTI overlay; file contents byte-identical to the reference's on the same detections
+    (tests/golden/preds/*): the voxel box is the fp32 product ``clip(box, 0, 1) * shape`` truncated to int, and the CSV's
+    score column holds what pandas prints for the 0-dim tensors the reference stores there (``tensor(0.9700)``)."""
+    boxes = np.asarray(boxes, dtype=np.float32).reshape(-1, 6)
+    scores = np.asarray(scores, dtype=np.float32).reshape(-1)
+    shape2 = np.asarray(tuple(img_shape) * 2, dtype=np.float32)
     infos, scores_map = {}, []
     for j in range(boxes.shape[0]):
         score = float(scores[j])
-        scores_map.append((j + 1, score))
+        scores_map.append((j + 1, scores[j]))
         if score < min_score or int(labels[j]) == 0:
             continue
         frac = [float(v) for v in boxes[j]]
-        vox = (np.clip(boxes[j], 0, 1) * np.array(img_shape * 2)).astype(int).tolist()
+        vox = (np.clip(boxes[j], np.float32(0), np.float32(1)) * shape2).astype(int).tolist()
         infos[j + 1] = (frac, vox, int(labels[j]), score)
     with open(pjoin(output_dir, f"sub-{subject}_preds.json"), "w") as f:
         json.dump(infos, f)
     with open(pjoin(output_dir, f"sub-{subject}_preds.csv"), "w") as f:
         f.write(",label_id,score\n")
         for i, (lid, sc) in enumerate(scores_map):
-            f.write(f"{i},{lid},{sc}\n")
+            f.write(f"{i},{lid},{str(torch.tensor(sc))}\n")
 
 
 def predict_example(args):

@@ -553,23 +553,57 @@ class LSSD3D(nn.Module):
             return sum(abs(p).sum() for p in self.parameters())
 
     # -- checkpoints (Lightning-compatible dict) ------------------------------------------------------
-    def save_checkpoint(self, path, optimizer=None):
+    @staticmethod
+    def _plain(v):
+        """Hyper-parameters as plain Python types (numpy scalars cast), so that the file loads with
+        ``torch.load(weights_only=True)`` — the only loader this package uses on a checkpoint."""
+        if isinstance(v, dict):
+            return {LSSD3D._plain(k): LSSD3D._plain(x) for k, x in v.items()}
+        if isinstance(v, (list, tuple)):
+            return type(v)(LSSD3D._plain(x) for x in v)
+        if isinstance(v, np.generic):
+            return v.item()
+        if isinstance(v, np.ndarray):
+            return v.tolist()
+        return v
+
+    def save_checkpoint(self, path, optimizer=None, scheduler=None):
+        """Lightning's key layout (``state_dict`` / ``hyper_parameters`` / ``epoch`` / ``global_step`` /
+        ``optimizer_states`` / ``lr_schedulers``, reference train.py:171-176,185) with tensors and plain types only.
+        ``optimizer`` may be a FusedAdam or a FusedTrainer (then its scheduler is saved too)."""
         ckpt = {"state_dict": {k: v.detach().cpu() for k, v in self.state_dict().items()},
-                "hyper_parameters": dict(self.hparams), "epoch": self.current_epoch, "global_step": self.global_step}
+                "hyper_parameters": self._plain(dict(self.hparams)), "epoch": int(self.current_epoch),
+                "global_step": int(self.global_step)}
+        if optimizer is not None and hasattr(optimizer, "opt"):  # a FusedTrainer
+            scheduler = optimizer.sch if scheduler is None else scheduler
+            optimizer = optimizer.opt
         if optimizer is not None:
-            ckpt["optimizer_states"] = [optimizer.state_dict()]
+            ckpt["optimizer_states"] = [self._plain(optimizer.state_dict())]
+        if scheduler is not None:
+            ckpt["lr_schedulers"] = [self._plain(scheduler.state_dict())]
         torch.save(ckpt, path)
+
+    @staticmethod
+    def read_checkpoint(path, map_location="cpu"):
+        """The one place a checkpoint file is opened: ``weights_only=True``, no fallback.  A Lightning ``.ckpt`` written by
+        the reference pickles arbitrary objects (callbacks, ``AttributeDict``) and is refused here: re-export it on a
+        trusted machine as ``{"state_dict": ..., "hyper_parameters": {plain types}}``."""
+        try:
+            return torch.load(path, map_location=map_location, weights_only=True)
+        except Exception as e:  # noqa: BLE001 - any unpickling refusal
+            raise RuntimeError(
+                f"{path}: not loadable with torch.load(weights_only=True) ({type(e).__name__}: {str(e).splitlines()[0][:200]}). "
+                "mslesions3d_amd never unpickles arbitrary objects from a checkpoint; re-export the file as a dict of "
+                "tensors and plain Python types (state_dict + hyper_parameters).") from e
 
     @classmethod
     def load_from_checkpoint(cls, path, map_location="cpu", **overrides):
-        try:
-            ckpt = torch.load(path, map_location=map_location, weights_only=True)
-        except Exception:
-            # own checkpoints carry a plain dict of hyper-parameters (np.float64 scales etc.)
-            ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        ckpt = cls.read_checkpoint(path, map_location)
         hp = dict(ckpt.get("hyper_parameters", {}))
         hp.update(overrides)
         hp = {k: v for k, v in hp.items() if k in cls.__init__.__code__.co_varnames}
+        if "aspect_ratios" in hp:  # JSON-ish round trips may have turned the feature indices into strings
+            hp["aspect_ratios"] = {int(k): v for k, v in hp["aspect_ratios"].items()}
         model = cls(**hp)
         model.load_state_dict(ckpt["state_dict"])
         model.current_epoch = int(ckpt.get("epoch", 0))

@@ -17,28 +17,38 @@ import numpy as np
 import torch
 
 
-def make_case(idx, image_size=(64, 64, 64), num_objects=(1, 5), object_size=(6, 14), random_seed=0):
-    """-> (image float32 (D,H,W) normalised, mask uint8, boxes (n,6) float32 fractional, labels (n,) int64)."""
+def generate_volume(idx, image_size=(64, 64, 64), num_objects=(1, 5), object_size=(6, 14), random_seed=0):
+    """generate_artificial_dataset.py:63-111 for ``n_classes = 1``, noise on: the float64 volume and mask the reference
+    hands to ``nib.save`` (same seed, same draw order: pinned bit for bit by tests/golden/datapath.npz) + the cube list."""
+    image_size = tuple(image_size)
+    lo, hi = sorted(object_size)
     np.random.seed(random_seed + idx)
     data = np.random.rand(*image_size)
-    mask = np.zeros(image_size, dtype=np.uint8)
+    mask = np.zeros_like(data)
     n_objects = np.random.randint(*num_objects)
-    boxes = []
+    cubes = []
     for _ in range(n_objects + 1):
-        size = np.random.randint(object_size[0], object_size[1])
+        size = np.random.randint(lo, hi)
         np.random.randint(0, 1)  # selected_class draw of the reference (n_classes = 1)
-        tl = [np.random.randint(0, image_size[i] - size) for i in range(3)]
+        tl = [np.random.randint(0, image_size[i] - size) for i in range(len(image_size))]
         sl = tuple(slice(t, t + size) for t in tl)
         data[sl] = data[sl] + 0.4
         data = data.clip(0, 1)
         mask[sl] = 1
-        boxes.append([tl[0] / image_size[0], tl[1] / image_size[1], tl[2] / image_size[2],
-                      (tl[0] + size - 1) / image_size[0], (tl[1] + size - 1) / image_size[1],
-                      (tl[2] + size - 1) / image_size[2]])
+        cubes.append((tl, size))
+    return data, mask, cubes
+
+
+def make_case(idx, image_size=(64, 64, 64), num_objects=(1, 5), object_size=(6, 14), random_seed=0):
+    """-> (image float32 (D,H,W) normalised, mask uint8, boxes (n,6) float32 fractional, labels (n,) int64)."""
+    data, mask, cubes = generate_volume(idx, image_size, num_objects, object_size, random_seed)
+    boxes = [[tl[0] / image_size[0], tl[1] / image_size[1], tl[2] / image_size[2],
+              (tl[0] + size - 1) / image_size[0], (tl[1] + size - 1) / image_size[1],
+              (tl[2] + size - 1) / image_size[2]] for tl, size in cubes]
     img = data.astype(np.float32)
     nz = img != 0
     img[nz] = (img[nz] - img[nz].mean()) / img[nz].std()
-    return img, mask, np.asarray(boxes, dtype=np.float32), np.ones(len(boxes), dtype=np.int64)
+    return img, mask.astype(np.uint8), np.asarray(boxes, dtype=np.float32), np.ones(len(boxes), dtype=np.int64)
 
 
 def make_batch_on_device(n, image_size, device, channels=1, num_objects=(1, 5), object_size=(6, 14), seed=0):

@@ -53,16 +53,17 @@ def build_parser():
 
 
 def example(args):
-    from .datasets import ExampleDataset
+    from .datasets import ExampleDataset, select_augmentations
     from .ssd3d import LSSD3D
     from .trainer import FusedTrainer
     torch.manual_seed(args.seed)
     layers = [int(x) for x in args.prediction_layers.split()]
     aspect_ratios = {l: [1.] for l in layers}
     scales = {int(k): v for k, v in args.scales.items()}
+    augmentations = select_augmentations(args.augmentations)  # train.py:132-145 (flip rotate90 translate scale)
     dataset = ExampleDataset(n_classes=args.n_classes, subject=args.subject, percentage=args.percentage,
                              num_workers=args.num_workers, batch_size=args.batch_size, data_dir=args.dataset_path,
-                             dataset_name=args.dataset_name)
+                             dataset_name=args.dataset_name, augmentations=augmentations, random_state=970205)
     dataset.setup(stage="fit")
     input_size = tuple(dataset.train_dataset[0]["img"].shape)[1:]
     threshold = args.threshold if len(args.threshold) > 1 else [args.threshold[0]]
@@ -80,13 +81,22 @@ def example(args):
     model.init()
     model = model.to("cuda")
     trainer = FusedTrainer(model)
+    first_epoch = 0
+    if args.checkpoint:
+        # resume_from_checkpoint (train.py:185): weights above, here the optimiser moments / step count, the scheduler
+        # phase and the epoch counter, so that the resumed run continues the interrupted one bit for bit
+        ckpt = LSSD3D.read_checkpoint(args.checkpoint)
+        if ckpt.get("optimizer_states"):
+            trainer.load_state_dict({"optimizer": ckpt["optimizer_states"][0],
+                                     "scheduler": (ckpt.get("lr_schedulers") or [None])[0]})
+            first_epoch = int(ckpt.get("epoch", -1)) + 1
     logdir = pjoin(args.logdir, args.experiment_name)
     os.makedirs(logdir, exist_ok=True)
     log = open(pjoin(logdir, "metrics.jsonl"), "a")
     best, bad_epochs, done = [], 0, False
     max_epochs = args.max_epochs if args.max_epochs else 10 ** 9
     max_iters = -1 if args.max_epochs else args.max_iterations
-    for epoch in range(max_epochs):
+    for epoch in range(first_epoch, max_epochs):
         model.current_epoch = epoch
         model.train()
         for batch in dataset.train_dataloader():
@@ -97,6 +107,10 @@ def example(args):
             if 0 < max_iters <= model.global_step:
                 done = True
                 break
+        if trainer.sch is not None:
+            # Lightning steps a scheduler returned by configure_optimizers once per epoch (interval="epoch") on top of
+            # the manual per-step call inside training_step: one extra cosine step per epoch
+            trainer.sch.step()
         model.eval()
         vals = [model.validation_step(b, i) for i, b in enumerate(dataset.test_dataloader())]
         avg = {k: float(torch.stack([v["log"][k] for v in vals]).mean()) for k in ("val_total_loss", "val_conf_loss", "val_loc_loss")}
@@ -115,7 +129,7 @@ def example(args):
         best.append((rec["avg_val_loss"], path))
         best.sort()
         if (rec["avg_val_loss"], path) in best[:3]:
-            model.save_checkpoint(path, trainer.opt)
+            model.save_checkpoint(path, trainer)
         for _, p in best[3:]:
             if os.path.exists(p):
                 os.remove(p)

@@ -3,7 +3,8 @@
 Restates the step the reference's Lightning loop performs around ``LSSD3D.training_step``
 (``lesions3d/ssd3d.py:467-531``) and ``configure_optimizers`` (``ssd3d.py:704-722``):
 forward -> MultiBox loss -> ``loss = conf + alpha * loc`` -> backward -> Adam(wd 5e-4, biases at 2*lr)
--> cosine schedule stepped once per training step (ssd3d.py:527-529).
+with the cosine schedule stepped once per training step INSIDE ``training_step`` (ssd3d.py:527-529), which
+Lightning's automatic optimisation runs within the optimiser closure: update k uses the LR after k scheduler steps.
 Used by the parity tests and as the timed CPU baseline of ``bench.py`` (kind "port").
 """
 import torch
@@ -31,7 +32,7 @@ def train_step(model, opt, sch, images, boxes, labels, threshold, alpha=1.0):
     conf, loc = multibox_loss(locs, scores, boxes, labels, model.priors_cxcycz, threshold)
     loss = conf + alpha * loc  # ssd3d.py:494
     loss.backward()
-    opt.step()
-    if sch is not None:
+    if sch is not None:  # ssd3d.py:527-529 runs inside the closure, i.e. before the parameter update
         sch.step()
+    opt.step()
     return float(loss.detach()), float(conf.detach()), float(loc.detach())

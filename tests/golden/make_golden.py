@@ -153,27 +153,34 @@ def gen_network(ref, tag, n, c_in, size, sample_stride):
         out[f"rm__{k}"] = sd[k + ".running_mean"].numpy().copy()
         out[f"rv__{k}"] = sd[k + ".running_var"].numpy().copy()
         out[f"nbt__{k}"] = sd[k + ".num_batches_tracked"].numpy().copy()
-    # two optimiser steps (ssd3d.py:704-722 + manual scheduler step ssd3d.py:527-529)
-    m2 = build_ref_model(ref, input_channels=c_in, input_size=size, lr=1e-3)
+    # two optimiser steps, driven the way Lightning's automatic optimisation drives the reference: the optimizer calls a
+    # closure that runs the reference's OWN training_step (which steps the scheduler itself, ssd3d.py:527-529) and the
+    # backward pass, then applies the update (ssd3d.py:704-722).  use_wandb=True routes its logging to the inert
+    # self.log; current_epoch = 1 skips the periodic mAP branch (ssd3d.py:497).
+    m2 = build_ref_model(ref, input_channels=c_in, input_size=size, lr=1e-3, use_wandb=True)
     m2.train()
+    m2.current_epoch = 1
     # the reference's configure_optimizers passes `verbose=` to the scheduler, which torch 2.10 no longer
     # accepts; the same optimizer/scheduler are built here from its parameter groups
     biases = [p for k, p in m2.named_parameters() if k.endswith(".bias")]
     others = [p for k, p in m2.named_parameters() if not k.endswith(".bias")]
     opt = torch.optim.Adam([{"params": biases, "lr": 2 * m2.lr}, {"params": others}], lr=m2.lr, weight_decay=0.0005)
     sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=40)
+    m2.lr_schedulers = lambda: sch
     losses = []
     for step in range(2):
         xs = detinit.make_volume_batch(50 + step, n, c_in, size)
         bs, ls = detinit.make_gt(60 + step, n, size)
-        opt.zero_grad(set_to_none=True)
-        lo, sc = m2(xs)
-        cf, lc = m2.loss_fn(lo, sc, bs, ls)
-        loss = cf + m2.loss_fn.alpha * lc
-        loss.backward()
-        opt.step()
-        sch.step()
-        losses.append([loss.item(), cf.item(), lc.item()])
+        batch = {"img": xs, "boxes": bs, "labels": ls, "subject": [str(i) for i in range(n)]}
+
+        def closure():
+            opt.zero_grad(set_to_none=True)
+            res = m2.training_step(batch)
+            res["loss"].backward()
+            losses.append([res["loss"].item(), res["log"]["train_conf_loss"].item(), res["log"]["train_loc_loss"].item()])
+            return res["loss"]
+
+        opt.step(closure)
     out["adam_losses"] = np.array(losses, dtype=np.float64)
     out["adam_lr"] = np.array(sch.get_last_lr(), dtype=np.float64)
     pn, ph = [], []

@@ -236,29 +236,53 @@ def test_full_gradients_against_oracle():
 
 
 def test_two_adam_steps_golden():
+    """Two optimisation steps through the reference-shaped API (training_step inside the optimiser closure, as
+    Lightning's automatic optimisation runs ssd3d.py:467-531: the scheduler steps before the update) against the
+    golden minted from the reference's own training_step."""
     g = golden("network_c64")
     size, n = (64, 64, 64), 2
     m = hip_model(1, size, lr=1e-3)
     m.train()
+    m.current_epoch = 1  # skips the periodic mAP branch, as in the golden run
     [opt], [sch] = m.configure_optimizers()
+    m._scheduler = sch
     losses = []
     for step in range(2):
         xs = detinit.make_volume_batch(50 + step, n, 1, size).to(DEV)
         bs, ls = detinit.make_gt(60 + step, n, size)
         opt.zero_grad()
-        lo, sc = m(xs)
-        cf, lc = m.loss_fn(lo, sc, [b.to(DEV) for b in bs], [t.to(DEV) for t in ls])
-        loss = cf + m.loss_fn.alpha * lc
-        loss.backward()
+        res = m.training_step({"img": xs, "boxes": bs, "labels": ls, "subject": ["0", "1"]})
+        res["loss"].backward()
         opt.step()
-        sch.step()
-        losses.append([loss.item(), cf.item(), lc.item()])
+        losses.append([res["loss"].item(), res["log"]["train_conf_loss"].item(), res["log"]["train_loc_loss"].item()])
     np.testing.assert_allclose(np.array(losses), g["adam_losses"], rtol=5e-4)
     np.testing.assert_allclose(sch.get_last_lr(), g["adam_lr"], rtol=1e-9)
     names = [k for k, _ in m.named_parameters()]
     assert names == list(g["adam_param_names"])
     norms = np.array([p.detach().double().norm().item() for _, p in m.named_parameters()])
     np.testing.assert_allclose(norms, g["adam_param_norm"], rtol=1e-4)
+
+
+def test_fused_trainer_two_steps_golden():
+    """The same two steps through FusedTrainer (the bench's hot loop): losses, LR and parameters vs the reference."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    g = golden("network_c64")
+    size, n = (64, 64, 64), 2
+    m = hip_model(1, size, lr=1e-3)
+    m.train()
+    tr = FusedTrainer(m)
+    losses = []
+    for step in range(2):
+        xs = detinit.make_volume_batch(50 + step, n, 1, size).to(DEV)
+        bs, ls = detinit.make_gt(60 + step, n, size)
+        out = tr.step(xs, bs, ls)
+        losses.append([out["loss"], out["conf"], out["loc"]])
+    np.testing.assert_allclose(np.array(losses), g["adam_losses"], rtol=5e-4)
+    np.testing.assert_allclose(tr.sch.get_last_lr(), g["adam_lr"], rtol=1e-9)
+    norms = np.array([p.detach().double().norm().item() for _, p in m.named_parameters()])
+    np.testing.assert_allclose(norms, g["adam_param_norm"], rtol=1e-4)
+    heads = np.stack([np.resize(p.detach().reshape(-1)[:4].cpu().numpy(), 4) for _, p in m.named_parameters()])
+    np.testing.assert_allclose(heads, g["adam_param_head4"], rtol=2e-3, atol=2e-6)
 
 
 def test_fused_step_equals_autograd_step():
@@ -273,6 +297,7 @@ def test_fused_step_equals_autograd_step():
     lo, sc = a(xs)
     cf, lc = a.loss_fn(lo, sc, [b.to(DEV) for b in bs], [t.to(DEV) for t in ls])
     (cf + a.loss_fn.alpha * lc).backward()
+    sch.step()  # ssd3d.py:527-529: inside training_step, i.e. before the update
     opt.step()
     b = hip_model(1, size, lr=1e-3)
     b.train()

@@ -1,0 +1,78 @@
+"""Host-side product code that needs no GPU: the detection metric and the checkpoint format."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden import cases
+from tests.util import golden
+
+
+@pytest.mark.parametrize("name", list(cases.map_cases().keys()))
+@pytest.mark.parametrize("ov", [0.1, 0.5])
+def test_product_calculate_map_matches_reference_golden(name, ov):
+    """``mslesions3d_amd.utils.calculate_mAP`` (what ``LSSD3D._metrics`` and ``predict.py`` call) against the outputs of the
+    reference's ``calculate_mAP(return_detail=True)`` (utils.py:242-396) on the same detections (map.npz)."""
+    from mslesions3d_amd.utils import calculate_mAP
+    g = golden("map")
+    c = cases.map_cases()[name]
+    T = lambda xs: [torch.from_numpy(np.asarray(x)) for x in xs]
+    dif = [torch.zeros(len(x), dtype=torch.bool) for x in c["true_labels"]]
+    d = calculate_mAP(T(c["det_boxes"]), T(c["det_labels"]), T(c["det_scores"]), T(c["true_boxes"]), T(c["true_labels"]), dif,
+                      min_overlap=ov, return_detail=True)
+    tag = f"{name}__{ov}"
+    for k in ("APs", "mAP", "precision", "recall", "f1_score", "n_true_boxes"):
+        np.testing.assert_allclose(float(d[k]), float(g[f"{tag}__{k}"]), rtol=1e-6, equal_nan=True)
+    for k in ("TP", "FP", "found_boxes_volumes_per_class", "not_found_boxes_volumes_per_class"):
+        np.testing.assert_allclose(np.asarray(d[k], np.float32), g[f"{tag}__{k}"], rtol=1e-6)
+    # the two-value form (utils.py:382-383) agrees with the detail dict
+    aps, m = calculate_mAP(T(c["det_boxes"]), T(c["det_labels"]), T(c["det_scores"]), T(c["true_boxes"]), T(c["true_labels"]),
+                           dif, min_overlap=ov)
+    np.testing.assert_allclose(m, float(g[f"{tag}__mAP"]), rtol=1e-6)
+    assert list(aps.keys()) == ["lesion"]
+
+
+def _small_model(**kw):
+    from mslesions3d_amd.ssd3d import LSSD3D
+    torch.manual_seed(3)
+    return LSSD3D(n_classes=2, input_channels=1, input_size=(64, 64, 64), threshold=[0.1, 0.2], lr=1e-3, **kw)
+
+
+def test_checkpoint_is_weights_only_loadable(tmp_path):
+    """Own checkpoints hold tensors and plain Python types only (numpy scalars cast), in Lightning's key layout, and load
+    through ``torch.load(weights_only=True)`` — there is no other loader."""
+    from mslesions3d_amd.ssd3d import LSSD3D
+    m = _small_model(scales={3: np.float64(0.1), 5: np.float32(0.2), 7: 0.3}, min_score=np.float64(0.25))
+    m.current_epoch, m.global_step = 3, 17
+    p = str(tmp_path / "own.ckpt")
+    m.save_checkpoint(p)
+    raw = torch.load(p, map_location="cpu", weights_only=True)
+    assert set(raw.keys()) >= {"state_dict", "hyper_parameters", "epoch", "global_step"}
+    assert type(raw["hyper_parameters"]["scales"][3]) is float and type(raw["hyper_parameters"]["min_score"]) is float
+    m2 = LSSD3D.load_from_checkpoint(p, top_k=7)
+    assert (m2.current_epoch, m2.global_step, m2.top_k) == (3, 17, 7)
+    assert m2.scales == {3: 0.1, 5: float(np.float32(0.2)), 7: 0.3}
+    for (k, a), (_, b) in zip(m.state_dict().items(), m2.state_dict().items()):
+        assert torch.equal(a, b), k
+
+
+class _Evil:
+    def __reduce__(self):
+        return (os.system, ("echo checkpoint code execution > /dev/null",))
+
+
+def test_checkpoint_with_pickled_object_is_refused(tmp_path):
+    """A file that needs arbitrary unpickling (what a reference Lightning .ckpt — or a hostile file — is) is refused with a
+    clear error; nothing retries it with ``weights_only=False``."""
+    from mslesions3d_amd.ssd3d import LSSD3D
+    m = _small_model()
+    p = str(tmp_path / "evil.ckpt")
+    with open(p, "wb") as f:
+        pickle.dump({"state_dict": {k: v for k, v in m.state_dict().items()}, "hyper_parameters": {"x": _Evil()}}, f)
+    with pytest.raises(RuntimeError, match="weights_only=True"):
+        LSSD3D.load_from_checkpoint(p)
+    import inspect
+    import mslesions3d_amd.ssd3d as S
+    assert "weights_only=False" not in inspect.getsource(S)
