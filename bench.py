@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--no-aggregate", action="store_true",
                     help="skip the two extra all-depthwise-layer passes after the timed region (rocprofv3 runs: keeps the "
                          "kernel statistics those of the training step alone)")
+    ap.add_argument("--no-events", action="store_true", help="no HIP-event pair around the roofline kernel inside the timed steps")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch and print a table (stderr)")
     return ap.parse_args()
 
@@ -122,7 +123,8 @@ def main():
     run(args.warmup)
     torch.cuda.synchronize()
     eng = model._engine
-    eng.start_profile(None if args.profile_all else {"dw_fwd1"})
+    if not args.no_events:
+        eng.start_profile(None if args.profile_all else {"dw_fwd1"})
     if world > 1 or rehearse:  # the rehearsal runs every collective of the N > 1 path on one rank
         dist.barrier()
     torch.cuda.synchronize()
@@ -134,7 +136,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    prof = eng.stop_profile()
+    prof = eng.stop_profile() if not args.no_events else {}
     # SURVEY 8(d)'s aggregate over ALL seven depthwise forwards, timed in situ in a short pass of its own (14 more
     # event records per step would perturb the timed region above): outside the timed region, not part of `value`
     dw_all = None

@@ -76,6 +76,9 @@ int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW);
 int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D, int H,
                       int W, int sd, int sh, int sw, void* stream);
 size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin);
+/* slabs ([32][32*ceil(Cin*27/32)] floats each) the three stem weight-gradient forms leave in `workspace`; with dw == NULL they
+ * skip their own reduction (deferred: msl_grad_reduce_batch kind 2) */
+int msl_stem_conv_bwd_weight_nslabs(int N, int D, int H, int W, int sd, int sh, int sw);
 int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D,
                              int H, int W, int sd, int sh, int sw, void* stream);
 
@@ -141,6 +144,11 @@ int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
 size_t msl_pwconv_bwd_weight_workspace_bytes(int N, int Cin, int Cout, int S);
 int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale, const float* in_shift, float* dw,
                           float* workspace, int N, int Cin, int Cout, int S, void* stream);
+/* the same as partial results: `out` = [nslabs][Cout][Cin] slabs whose sum (slab order) is dW; nslabs == 1: dW itself.
+ * The training step folds the slabs of every layer in one msl_grad_reduce_batch (kind 0). */
+int msl_pwconv_bwd_weight_nslabs(int N, int Cin, int Cout, int S);
+int msl_pwconv_bwd_weight_slabs(const float* dy, const float* z, const float* in_scale, const float* in_shift,
+                                float* out, int N, int Cin, int Cout, int S, void* stream);
 
 /* ---- detection heads: loc (C->12) + cls (C->2*ncls) k3 p1 convs, permute/view/cat fused : ssd3d.py:113-169 - */
 size_t msl_head_packed_weight_elems(int C, int ncls);
@@ -155,6 +163,8 @@ int msl_head_grad_pack(const float* dlocs, const float* dscores, float* dO_pad, 
 int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int N, int C, int D, int H, int W,
                            int ncls, void* stream);
 size_t msl_head_bwd_weight_workspace_bytes(int N, int C, int D, int H, int W, int ncls);
+/* slabs msl_head_conv_bwd_weight leaves in `workspace`; dloc_w == NULL skips its own reduction (deferred: kind 3) */
+int msl_head_conv_bwd_weight_nslabs(int N, int C, int D, int H, int W);
 int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dloc_w, float* dcl_w, float* dloc_b,
                              float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls,
                              void* stream);
@@ -221,6 +231,16 @@ int msl_detect_objects(const float* locs, const float* scores, const float* prio
 int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp,
                   const unsigned char* is_bias, int n, void* stream);
 int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream);
+/* Batched gradient reduction (autograd's accumulation of the conv weight gradients, ssd3d.py:467-531 backward): the
+ * weight-gradient kernels leave partial sums (fp32 slabs / fp64 partials) in their workspaces; ONE launch folds the
+ * listed ones into the flat gradient arena in a fixed order.  The table is built on the host with _table_set (which
+ * returns the number of workgroups of the entry; first_block = running sum) and uploaded by the caller.
+ * kind 0: fp32 slabs [nslabs][stride] -> dst[i];  1: fp64 partials [count][nslabs] -> dst[i];  2: stem slabs, padded
+ * [32][32*p1] image -> dst[co*p0 + k];  3: head slabs -> dst = dloc_w, dst2 = dcl_w (p0 = C, p1 = MT, p2 = 12 + 2*ncls). */
+size_t msl_grad_reduce_entry_bytes(void);
+int msl_grad_reduce_table_set(void* host_table, int index, int first_block, int kind, const void* src, float* dst,
+                              float* dst2, int nslabs, int count, long long stride, int p0, int p1, int p2);
+int msl_grad_reduce_batch(const void* table, int n_entries, int total_blocks, void* stream);
 /* stream fork/join (hipEvent with timing disabled): record on the producer stream, wait on the consumer stream */
 int msl_event_create(void** out);
 int msl_event_create_timed(void** out);                       /* timing-enabled event (launch-duration measurements) */
@@ -238,6 +258,11 @@ int msl_graph_destroy(void* exec);
  * msl_program_fn_id(); slots = n x stride raw 64-bit argument values; *failed_at = index of the failing call */
 int msl_program_fn_id(const char* name);
 int msl_run_program(const int* fn_ids, const unsigned long long* slots, int stride, int n, int* failed_at);
+/* the same issued by two host threads: calls with lane[i] == 1 (the side streams' work) go to a persistent worker thread,
+ * lane 0 (the dependency chain's stream) stays with the caller; wait_for[i] >= 0 names the msl_event_record entry that
+ * must have been issued before the msl_stream_wait_event of entry i.  Every stream must belong to one lane. */
+int msl_run_program_mt(const int* fn_ids, const unsigned long long* slots, int stride, int n, const int* lane,
+                       const int* wait_for, int device, int* failed_at);
 /* asynchronous 32-bit fill (used to clear flags / counters inside a launch sequence) */
 int msl_fill_u32(void* dst, unsigned int value, size_t count, void* stream);
 

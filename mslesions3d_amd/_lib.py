@@ -56,6 +56,13 @@ _SIGNATURES = {
     "msl_pwconv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I]),
     "msl_pwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_pwconv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I]),
+    "msl_pwconv_bwd_weight_slabs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_stem_conv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "msl_head_conv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I, _I]),
+    "msl_grad_reduce_entry_bytes": (_Z, []),
+    "msl_grad_reduce_table_set": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _Q, _I, _I, _I]),
+    "msl_grad_reduce_batch": (_I, [_P, _I, _I, _P]),
     "msl_head_packed_weight_elems": (_Z, [_I, _I]),
     "msl_head_pack_weights": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "msl_head_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
@@ -80,6 +87,7 @@ _SIGNATURES = {
     "msl_nan_flag": (_I, [_P, _Z, _P, _I, _P]),
     "msl_program_fn_id": (_I, [_P]),
     "msl_run_program": (_I, [_P, _P, _I, _I, _P]),
+    "msl_run_program_mt": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
     "msl_graph_begin": (_I, [_P]),
     "msl_graph_end": (_I, [_P, _P]),
@@ -145,18 +153,43 @@ def _slot(value, ctype):
     return int(value) & 0xFFFFFFFFFFFFFFFF
 
 
-def compile_program(prog, timed_tags=()):
-    """Recorded program -> list of segments: ("native", fn_ids, slots, n, tags) runs in ONE foreign call through the
-    generated trampolines (csrc/program_runner.hip); ("hook", callable) are the Python callbacks in between;
-    launches whose tag is in ``timed_tags`` stay individual ("timed", (fn, args, tag)) so an event pair can wrap them."""
+def _entry_stream(name, args):
+    if name == "msl_event_record":
+        return args[1]
+    if name == "msl_stream_wait_event":
+        return args[0]
+    return args[-1]
+
+
+def compile_program(prog, timed_tags=(), main_stream=None, device=0):
+    """Recorded program -> list of segments: ("native", fn_ids, slots, n, tags, lanes, wait_for) runs in ONE foreign call
+    through the generated trampolines (csrc/program_runner.hip); ("hook", callable) are the Python callbacks in between;
+    launches whose tag is in ``timed_tags`` get an event record in front and behind (patched per replay).
+
+    ``main_stream``: issue the segment with two host threads (msl_run_program_mt) - the calls on that stream stay with
+    the caller, everything else goes to the worker thread; a stream-wait is held back until the event record it refers
+    to has been issued.  None (or MSL_ENQUEUE_THREADS=1): one thread."""
     lib = load()
-    segs, ids, slots, tags, patches = [], [], [], [], []
+    two = main_stream is not None and os.environ.get("MSL_ENQUEUE_THREADS", "2") != "1"
+    segs, ids, slots, tags, patches, lanes, waits = [], [], [], [], [], [], []
+    last_record = {}
 
     def flush():
         if ids:
             n = len(ids)
-            segs.append(("native", (ctypes.c_int * n)(*ids), (ctypes.c_ulonglong * (n * _SLOT_STRIDE))(*slots), n, list(tags)))
-            ids.clear(), slots.clear(), tags.clear()
+            mt = None
+            if two and any(lanes) and not all(lanes):
+                mt = ((ctypes.c_int * n)(*lanes), (ctypes.c_int * n)(*waits), int(device))
+            segs.append(("native", (ctypes.c_int * n)(*ids), (ctypes.c_ulonglong * (n * _SLOT_STRIDE))(*slots), n, list(tags), mt))
+            ids.clear(), slots.clear(), tags.clear(), lanes.clear(), waits.clear()
+            last_record.clear()  # records of an earlier segment have been issued by the time this one starts
+
+    def push(fid, row, tag, lane, wait=-1):
+        ids.append(fid)
+        slots.extend(row + [0] * (_SLOT_STRIDE - len(row)))
+        tags.append(tag)
+        lanes.append(lane)
+        waits.append(wait)
 
     for fn, args, tag in prog:
         if fn is None:
@@ -164,14 +197,13 @@ def compile_program(prog, timed_tags=()):
             segs.append(("hook", args))
             continue
         name = fn.__name__
+        stream = _entry_stream(name, args)
+        lane = 0 if (main_stream is None or stream == main_stream) else 1
         timed = tag in timed_tags
         if timed:  # event record / launch / event record back to back inside the native segment
             rec = _fn_ids.setdefault("msl_event_record", lib.msl_program_fn_id(b"msl_event_record"))
-            stream = args[-1]
             patches.append((len(segs), len(ids) * _SLOT_STRIDE, (len(ids) + 2) * _SLOT_STRIDE, tag))
-            ids.append(rec)
-            slots.extend([0, _slot(stream, _P)] + [0] * (_SLOT_STRIDE - 2))
-            tags.append("event")
+            push(rec, [0, _slot(stream, _P)], "event", lane)
         fid = _fn_ids.get(name)
         if fid is None:
             fid = _fn_ids[name] = lib.msl_program_fn_id(name.encode())
@@ -180,13 +212,14 @@ def compile_program(prog, timed_tags=()):
         argtypes = _SIGNATURES[name][1]
         row = [_slot(a, t) for a, t in zip(args, argtypes)]
         assert len(row) == len(argtypes) <= _SLOT_STRIDE, name
-        ids.append(fid)
-        slots.extend(row + [0] * (_SLOT_STRIDE - len(row)))
-        tags.append(tag)
+        wait = -1
+        if name == "msl_stream_wait_event":
+            wait = last_record.get(args[1], -1)
+        push(fid, row, tag, lane, wait)
+        if name == "msl_event_record":
+            last_record[args[0]] = len(ids) - 1
         if timed:
-            ids.append(rec)
-            slots.extend([0, _slot(stream, _P)] + [0] * (_SLOT_STRIDE - 2))
-            tags.append("event")
+            push(rec, [0, _slot(stream, _P)], "event", lane)
     flush()
     return {"segments": segs, "patches": patches}
 
@@ -219,59 +252,13 @@ def replay_native(compiled, sink=None):
         if seg[0] == "hook":
             seg[1]()
         else:
-            rc = lib.msl_run_program(seg[1], seg[2], _SLOT_STRIDE, seg[3], ctypes.byref(failed))
+            if seg[5] is not None:
+                rc = lib.msl_run_program_mt(seg[1], seg[2], _SLOT_STRIDE, seg[3], seg[5][0], seg[5][1], seg[5][2],
+                                            ctypes.byref(failed))
+            else:
+                rc = lib.msl_run_program(seg[1], seg[2], _SLOT_STRIDE, seg[3], ctypes.byref(failed))
             if rc:
                 check(rc, f"launch program entry {failed.value} ({seg[4][failed.value]})")
-
-
-def capture_graph(prog, stream):
-    """Capture a recorded launch program (single process, no Python hooks) into an executable HIP graph."""
-    if any(fn is None for fn, _, _ in prog):
-        raise HipKernelError("a launch program with Python hooks cannot be captured into a HIP graph")
-    lib = load()
-    check(lib.msl_graph_begin(stream), "msl_graph_begin")
-    try:
-        replay(prog)
-    except Exception:
-        out = ctypes.c_void_p()
-        lib.msl_graph_end(stream, ctypes.byref(out))
-        raise
-    out = ctypes.c_void_p()
-    check(lib.msl_graph_end(stream, ctypes.byref(out)), "msl_graph_end")
-    return out.value
-
-
-def capture_segments(prog, stream, split_tags):
-    """Like capture_graph, but the launches whose tag is in ``split_tags`` stay individual launches (so that an
-    event pair can be recorded around them): -> list of ("graph", exec) / ("call", (fn, args, tag)) parts."""
-    parts, cur = [], []
-    for item in prog:
-        if item[2] in split_tags and item[0] is not None:
-            if cur:
-                parts.append(("graph", capture_graph(cur, stream)))
-                cur = []
-            parts.append(("call", item))
-        else:
-            cur.append(item)
-    if cur:
-        parts.append(("graph", capture_graph(cur, stream)))
-    return parts
-
-
-def run_segments(parts, stream, sink, event_factory):
-    lib = load()
-    for kind, payload in parts:
-        if kind == "graph":
-            check(lib.msl_graph_launch(payload, stream), "msl_graph_launch")
-        else:
-            fn, args, tag = payload
-            e0, e1 = event_factory(), event_factory()
-            e0.record()
-            rc = fn(*args)
-            e1.record()
-            sink.setdefault(tag, []).append((e0, e1))
-            if rc:
-                check(rc, tag)
 
 
 def ptr(t):

@@ -541,7 +541,8 @@ int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int st
   return N * msl::cdiv(OD * OH * OW, BW_CHUNK);
 }
 
-// dw (C,27) from dy and the raw input x (+ its affine); partials: fp64 [C*27][NP]
+// dw (C,27) from dy and the raw input x (+ its affine); partials: fp64 [C*27][NP], NP = msl_dwconv_bwd_weight_num_partials.
+// dw == NULL: leave the partials (deferred reduction, msl_grad_reduce_batch kind 1).
 int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,
                           double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
@@ -550,6 +551,7 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
   {
     const int rc = msl_dwconv_bwd_weight_tiled(dy, x, in_scale, in_shift, partials, N, C, D, H, W, stride, stream);
     if (rc == MSL_OK) {
+      if (!dw) return MSL_OK;
       const int NPt = msl_dwconv_bwd_weight_tiled_num_partials(N, C, D, H, W, stride);
       hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, NPt, dw, C * 27);
       MSL_LAUNCH_CHECK();
@@ -562,6 +564,7 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
   hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(msl::cdiv(total_items, 4)), dim3(256), 0, st, dy, x, in_scale, in_shift,
                      partials, C, D, H, W, OD, OH, OW, stride, chunks, N * chunks, total_items);
   MSL_LAUNCH_CHECK();
+  if (!dw) return MSL_OK;
   hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, N * chunks, dw, C * 27);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

@@ -248,26 +248,31 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
   }
 }
 
-// dW slabs.  grid (nchunk_blocks, C/16); block = 4 waves = 4 consecutive position chunks of `steps` MFMA
-// k-steps (4 positions each).  Every wave keeps the 27 tap accumulators (16 co x 16 ci) of its ci tile.
+// dW slabs.  grid (position blocks, C/16, 3); block = 4 waves = 4 consecutive position chunks of `steps` MFMA k-steps
+// (4 positions each).  A workgroup owns the 9 taps of ONE kd plane of its 16-channel tile (16 co x 16 ci x 9 taps): with
+// the taps split three ways the same number of workgroups needs a third of the position blocks, i.e. a third of the
+// partial-sum slabs (every position block costs one slab of the whole weight tensor), and a wave carries 9 instead of
+// 27 accumulator tiles.  The bias gradient sum_p dO[co][p] rides along as one more MFMA per step against a B operand
+// of ones (workgroups with blockIdx.y == 0 && kd == 0 only), so dO is not read a second time by a kernel of its own.
 template <int MT>
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __restrict__ dO_pad,
                                                               const float* __restrict__ a_pad,
-                                                              float* __restrict__ slabs, int N, int C, int D,
-                                                              int H, int W, int steps) {
-  extern __shared__ __align__(16) float red[];  // [27*MT][256]
+                                                              float* __restrict__ slabs, float* __restrict__ bias_slabs,
+                                                              int N, int C, int D, int H, int W, int steps) {
+  extern __shared__ __align__(16) float red[];  // [(9 + 1)*MT][256]
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int j = lane & 15, q = lane >> 4;
   const int S = D * H * W, Hp = H + 2, Wp = W + 2;
   const size_t volp = (size_t)(D + 2) * Hp * Wp;
   const int total = N * S;
-  const int ct = blockIdx.y;
+  const int ct = blockIdx.y, kd = blockIdx.z;
+  const bool do_bias = ct == 0 && kd == 0;
   const int chunk = blockIdx.x * 4 + wv;
   const int pbeg = chunk * steps * 4;
 
-  f32x4 acc[27 * MT];
+  f32x4 acc[10 * MT];  // [0, 9*MT): taps (kh, kw) of plane kd; [9*MT, 10*MT): bias
 #pragma unroll
-  for (int i = 0; i < 27 * MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 10 * MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int s = 0; s < steps; ++s) {
     int gp = pbeg + s * 4 + q;  // global position index over (n, d, h, w)
@@ -282,25 +287,28 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __res
       const float v = dO_pad[((size_t)n * 16 * MT + m * 16 + j) * volp + off + (size_t)Hp * Wp + Wp + 1];
       a[m] = ok ? v : 0.f;
     }
-    const float* bp = a_pad + ((size_t)n * C + ct * 16 + j) * volp + off;
+    const float* bp = a_pad + ((size_t)n * C + ct * 16 + j) * volp + off + (size_t)kd * Hp * Wp;
+    float b[9];
 #pragma unroll
-    for (int kd = 0; kd < 3; ++kd)
+    for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+      for (int kw = 0; kw < 3; ++kw) b[kh * 3 + kw] = bp[kh * Wp + kw];
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const int tap = kd * 9 + kh * 3 + kw;
-          const float b = bp[(kd * Hp + kh) * Wp + kw];
+    for (int t = 0; t < 9; ++t)
 #pragma unroll
-          for (int m = 0; m < MT; ++m)
-            acc[tap * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b, acc[tap * MT + m], 0, 0, 0);
-        }
+      for (int m = 0; m < MT; ++m)
+        acc[t * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[t], acc[t * MT + m], 0, 0, 0);
+    if (do_bias) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+        acc[9 * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], 1.0f, acc[9 * MT + m], 0, 0, 0);
+    }
   }
   // fixed-order reduction over the 4 waves
   for (int w2 = 3; w2 >= 1; --w2) {
     if (wv == w2) {
 #pragma unroll
-      for (int i = 0; i < 27 * MT; ++i)
+      for (int i = 0; i < 10 * MT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float* p = red + ((size_t)i * 4 + r) * 64 + lane;
@@ -312,12 +320,20 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __res
   }
   if (wv == 0) {
     // slabs[blockIdx.x][ct][tap][mt][co_local 16][ci_local 16]
-    float* out = slabs + ((size_t)blockIdx.x * gridDim.y + ct) * (27 * MT * 256);
+    float* out = slabs + (((size_t)blockIdx.x * gridDim.y + ct) * 27 + kd * 9) * (MT * 256);
 #pragma unroll
-    for (int i = 0; i < 27 * MT; ++i)
+    for (int i = 0; i < 9 * MT; ++i)
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         out[(size_t)i * 256 + (4 * q + r) * 16 + j] = acc[i][r] + red[((size_t)i * 4 + r) * 64 + lane];
+    if (do_bias && j == 0) {  // every column of the ones-product holds the row sums: take column 0
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bias_slabs[(size_t)blockIdx.x * 16 * MT + m * 16 + 4 * q + r] =
+              acc[9 * MT + m][r] + red[((size_t)(9 * MT + m) * 4 + r) * 64 + lane];
+    }
   }
 }
 
@@ -348,32 +364,16 @@ __global__ __launch_bounds__(256) void head_bwd_weight_reduce_kernel(const float
   else dcl_w[((size_t)(co - 12) * C + ci) * 27 + tap] = s;
 }
 
-// dbias[co] = sum_{n,P} dO[co][P]  (sums the zero halo as well)
-__global__ __launch_bounds__(256) void head_bias_grad_kernel(const float* __restrict__ dO_pad,
-                                                             float* __restrict__ dloc_b, float* __restrict__ dcl_b,
-                                                             int N, int CO, size_t volp) {
-  __shared__ double scratch[8];
-  const int co = blockIdx.x;
-  double s = 0.0;
-  for (int n = 0; n < N; ++n) {
-    const float* p = dO_pad + ((size_t)n * CO + co) * volp;
-    float part = 0.f;
-    size_t i = threadIdx.x;
-    for (; i + 7 * 256 < volp; i += 8 * 256) {  // 8 independent loads in flight; additions in index order
-      float v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = p[i + (size_t)u * 256];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) part += v[u];
-    }
-    for (; i < volp; i += 256) part += p[i];
-    s += (double)part;
-  }
-  const double t = msl::block_sum(s, scratch);
-  if (threadIdx.x == 0) {
-    if (co < 12) dloc_b[co] = (float)t;
-    else dcl_b[co - 12] = (float)t;
-  }
+// dbias[co] = sum over the position blocks' partial row sums (fixed order); one wave
+__global__ __launch_bounds__(64) void head_bias_reduce_kernel(const float* __restrict__ bias_slabs,
+                                                              float* __restrict__ dloc_b, float* __restrict__ dcl_b,
+                                                              int CO, int nslabs, int co_total) {
+  const int co = threadIdx.x;
+  if (co >= co_total) return;
+  float s = 0.f;
+  for (int k = 0; k < nslabs; ++k) s += bias_slabs[(size_t)k * CO + co];
+  if (co < 12) dloc_b[co] = s;
+  else dcl_b[co - 12] = s;
 }
 
 inline int head_mt(int ncls) { return (12 + 2 * ncls + 15) / 16; }
@@ -388,10 +388,12 @@ inline int head_ksg(int N, int C, int S) {
 struct HwPlan {
   int steps, nblocks;
 };
+// Position blocks of the weight-gradient kernel: tiles = (C/16) x 3 tap planes; about 256 workgroups in total, at least 8
+// MFMA k-steps per wave.  Every position block costs one partial slab of the whole weight tensor.
 inline HwPlan head_bw_plan(int N, int C, int S) {
   const int total_steps = msl::cdiv(N * S, 4);
-  const int tiles = C / 16;
-  int want_blocks = std::max(1, 512 / tiles);  // blocks along the position axis
+  const int tiles = (C / 16) * 3;
+  int want_blocks = std::max(1, 256 / tiles);  // blocks along the position axis
   int steps = std::max(8, msl::cdiv(total_steps, want_blocks * 4));
   HwPlan p;
   p.steps = steps;
@@ -467,11 +469,21 @@ int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int
   return MSL_OK;
 }
 
+// workspace = [nblocks][C/16][27*MT][16][16] weight slabs followed by [nblocks][16*MT] bias slabs
 size_t msl_head_bwd_weight_workspace_bytes(int N, int C, int D, int H, int W, int ncls) {
   HwPlan p = head_bw_plan(N, C, D * H * W);
-  return (size_t)p.nblocks * (C / 16) * 27 * head_mt(ncls) * 256 * sizeof(float);
+  return ((size_t)p.nblocks * (C / 16) * 27 * head_mt(ncls) * 256 + (size_t)p.nblocks * 16 * head_mt(ncls)) * sizeof(float);
 }
 
+// number of slabs msl_head_conv_bwd_weight leaves in its workspace
+int msl_head_conv_bwd_weight_nslabs(int N, int C, int D, int H, int W) {
+  if (N <= 0 || C % 16 != 0 || D <= 0 || H <= 0 || W <= 0) return MSL_ERR_ARG;
+  return head_bw_plan(N, C, D * H * W).nblocks;
+}
+
+// dloc_w == NULL (then dcl_w / dloc_b / dcl_b are ignored): leave the partial slabs in `workspace` (deferred reduction:
+// msl_grad_reduce_batch kind 3 for the weights, kind 0 on the bias slabs at float offset nslabs*(C/16)*27*MT*256 with
+// stride 16*MT: rows 0-11 -> dloc_b, rows 12.. -> dcl_b).
 int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dloc_w, float* dcl_w,
                              float* dloc_b, float* dcl_b, float* workspace, int N, int C, int D, int H, int W,
                              int ncls, void* stream) {
@@ -479,23 +491,21 @@ int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dlo
   const int S = D * H * W, MT = head_mt(ncls), co_total = 12 + 2 * ncls;
   HwPlan p = head_bw_plan(N, C, S);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(p.nblocks, C / 16);
-  const size_t lds = (size_t)27 * MT * 256 * sizeof(float);
+  dim3 grid(p.nblocks, C / 16, 3);
+  const size_t lds = (size_t)10 * MT * 256 * sizeof(float);
+  float* bias_slabs = workspace + (size_t)p.nblocks * (C / 16) * 27 * MT * 256;
   if (MT == 1) {
-    hipLaunchKernelGGL(head_bwd_weight_kernel<1>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, N, C, D, H, W, p.steps);
+    hipLaunchKernelGGL(head_bwd_weight_kernel<1>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
   } else {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(head_bwd_weight_kernel<2>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(head_bwd_weight_kernel<2>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, N, C, D, H, W, p.steps);
+    hipLaunchKernelGGL(head_bwd_weight_kernel<2>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
   }
   MSL_LAUNCH_CHECK();
+  if (!dloc_w) return MSL_OK;
   const int total = co_total * C * 27;
   hipLaunchKernelGGL(head_bwd_weight_reduce_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, st, workspace,
                      dloc_w, dcl_w, C, MT, p.nblocks, co_total);
   MSL_LAUNCH_CHECK();
-  const size_t volp = (size_t)(D + 2) * (H + 2) * (W + 2);
-  hipLaunchKernelGGL(head_bias_grad_kernel, dim3(co_total), dim3(256), 0, st, dO_pad, dloc_b, dcl_b, N, 16 * MT, volp);
+  hipLaunchKernelGGL(head_bias_reduce_kernel, dim3(1), dim3(64), 0, st, bias_slabs, dloc_b, dcl_b, 16 * MT, p.nblocks, co_total);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -30,6 +30,145 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   }
 }
 
+// ---- batched gradient reduction ---------------------------------------------------------------------------------
+// Every weight-gradient kernel of the step that splits its position range over workgroups leaves PARTIAL results
+// (fp32 slabs or fp64 per-element partials) in its workspace; ONE launch of this kernel folds all of them into the flat
+// gradient arena in a fixed order (slab 0, 1, 2, ... per output element: run-to-run bit-identical, no float atomics).
+// It replaces ~20 tiny per-layer reduce launches of the step (slab_reduce / dw finalize / head reduce / stem reduce).
+// A workgroup produces 32 output elements of one table entry; it finds its entry by scanning the (<= 64) first_block
+// fields, which are wave-uniform scalar loads.
+struct GradReduceEntry {   // 64 bytes, filled on the host by msl_grad_reduce_table_set
+  const void* src;
+  float* dst;
+  float* dst2;
+  long long stride;        // slab-major kinds: elements between two slabs
+  int kind, nslabs, count, first_block;
+  int p0, p1, p2, pad;
+};
+enum { GR_SLAB_F32 = 0, GR_ELEM_F64 = 1, GR_STEM_F32 = 2, GR_HEAD_F32 = 3 };
+
+// Output address of element i of a slab-major entry (nullptr: padding, nothing to store).
+__device__ __forceinline__ float* grad_reduce_dst(const GradReduceEntry& en, int i) {
+  if (en.kind == GR_SLAB_F32) return en.dst + i;
+  if (en.kind == GR_STEM_F32) {  // padded [32][32*NT] image -> dw[co][K]   (p0 = K, p1 = NT)
+    const int co = i / (32 * en.p1), k = i % (32 * en.p1);
+    return k < en.p0 ? en.dst + (size_t)co * en.p0 + k : nullptr;
+  }
+  // GR_HEAD_F32: i walks a slab in STORAGE order [ct][tap][mt][co16][ci16] (coalesced slab reads; the scattered accesses
+  // are the `count` writes, not the nslabs * count reads)   (p0 = C, p1 = MT, p2 = co_total)
+  const int C = en.p0, MT = en.p1;
+  const int cil = i & 15, col = (i >> 4) & 15, r = i >> 8;
+  const int mt = r % MT, tap = (r / MT) % 27, ct = r / (MT * 27);
+  const int co = mt * 16 + col, ci = ct * 16 + cil;
+  return co >= en.p2 ? nullptr
+         : co < 12   ? en.dst + ((size_t)co * C + ci) * 27 + tap
+                     : en.dst2 + ((size_t)(co - 12) * C + ci) * 27 + tap;
+}
+
+// Few slabs (<= GR_FEW): a thread owns 4 consecutive outputs (16-byte slab reads, all slabs' loads in flight at once),
+// 1024 outputs per workgroup - the workgroup count, not the bytes, is what this launch costs.
+constexpr int GR_FEW = 16;
+__host__ __device__ __forceinline__ bool grad_reduce_few(int kind, int nslabs, int count, long long stride) {
+  return kind != GR_ELEM_F64 && nslabs <= GR_FEW && count % 4 == 0 && stride % 4 == 0;
+}
+
+__global__ __launch_bounds__(256) void grad_reduce_batch_kernel(const GradReduceEntry* __restrict__ table, int n_entries) {
+  __shared__ float lds[8 * 33];
+  __shared__ double ldsd[8 * 33];
+  int e = 0;
+  for (int k = 1; k < n_entries; ++k)
+    if ((int)blockIdx.x >= table[k].first_block) e = k;
+  const GradReduceEntry en = table[e];
+  const int blk = blockIdx.x - en.first_block;
+  const int li = threadIdx.x & 31, g = threadIdx.x >> 5;
+  if (en.kind == GR_ELEM_F64) {
+    // partials of one element are contiguous: 32 lanes walk them (coalesced), 8 elements per pass, 4 passes
+    const double* src = (const double*)en.src;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int i = blk * 32 + pass * 8 + g;
+      double s = 0.0;
+      if (i < en.count) {
+        const double* ps = src + (size_t)i * en.nslabs;
+        int p = li;
+        for (; p + 7 * 32 < en.nslabs; p += 8 * 32) {  // 8 independent loads in flight; additions in index order
+          double v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) v[u] = ps[p + u * 32];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; p < en.nslabs; p += 32) s += ps[p];
+      }
+      ldsd[g * 33 + li] = s;
+      __syncthreads();
+      if (li == 0 && i < en.count) {
+        double t = 0.0;
+#pragma unroll
+        for (int u = 0; u < 32; ++u) t += ldsd[g * 33 + u];
+        en.dst[i] = (float)t;
+      }
+      __syncthreads();
+    }
+    return;
+  }
+  if (en.pad == 0 && grad_reduce_few(en.kind, en.nslabs, en.count, en.stride)) {
+    const int i = blk * 1024 + threadIdx.x * 4;
+    if (i >= en.count) return;
+    const float* p = (const float*)en.src + i;
+    float4 s = {0.f, 0.f, 0.f, 0.f};
+    int k = 0;
+    for (; k + 4 <= en.nslabs; k += 4) {  // 4 independent 16-byte loads in flight; additions in slab order
+      float4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const float4*>(p + (size_t)(k + u) * en.stride);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        s.x += v[u].x; s.y += v[u].y; s.z += v[u].z; s.w += v[u].w;
+      }
+    }
+    for (; k < en.nslabs; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(p + (size_t)k * en.stride);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (en.kind == GR_SLAB_F32) {
+      *reinterpret_cast<float4*>(en.dst + i) = s;
+    } else {
+      const float vals[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float* o = grad_reduce_dst(en, i + u);
+        if (o) *o = vals[u];
+      }
+    }
+    return;
+  }
+  // many slabs: 32 outputs x 8 slab groups per workgroup; output i of this entry sits at src[k * stride + i] in slab k
+  const int i = blk * 32 + li;
+  float* out = i < en.count ? grad_reduce_dst(en, i) : nullptr;
+  float s = 0.f;
+  if (i < en.count) {
+    const float* p = (const float*)en.src + i;
+    int k = g;
+#pragma unroll 1
+    for (; k + 56 < en.nslabs; k += 64) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = p[(size_t)(k + 8 * u) * en.stride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    for (; k < en.nslabs; k += 8) s += p[(size_t)k * en.stride];
+  }
+  lds[g * 33 + li] = s;
+  __syncthreads();
+  if (g == 0 && out) {
+    float t = 0.f;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t += lds[u * 33 + li];
+    *out = t;
+  }
+}
+
 __global__ __launch_bounds__(256) void nan_flag_kernel(const float* __restrict__ x, size_t n, int* __restrict__ flag,
                                                        int bit) {
   bool bad = false;
@@ -46,6 +185,34 @@ int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_
   if (n <= 0) return MSL_ERR_ARG;
   hipLaunchKernelGGL(adam_kernel, dim3(min(msl::cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, params,
                      grads, exp_avg, exp_avg_sq, hp, is_bias, n);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+size_t msl_grad_reduce_entry_bytes(void) { return sizeof(GradReduceEntry); }
+
+// Fill entry `index` of a HOST table (uploaded by the caller) and return the number of workgroups it needs (< 0: bad
+// argument); `first_block` = sum of the counts returned for the entries before it.
+//   kind 0  fp32 slabs  [nslabs][stride >= count]           -> dst[i]                       (pointwise weight gradients)
+//   kind 1  fp64 partials [count][nslabs]                    -> dst[i]                       (depthwise weight gradients)
+//   kind 2  fp32 slabs of the padded stem image [32][32*p1]  -> dst[co*p0 + k], k < p0       (stem; count = 1024 * p1)
+//   kind 3  fp32 head slabs (msl_head_conv_bwd_weight)       -> dst = dloc_w, dst2 = dcl_w   (p0 = C, p1 = MT, p2 = 12+2*ncls;
+//                                                                                            count = stride = (C/16)*27*MT*256)
+int msl_grad_reduce_table_set(void* host_table, int index, int first_block, int kind, const void* src, float* dst,
+                              float* dst2, int nslabs, int count, long long stride, int p0, int p1, int p2) {
+  if (!host_table || index < 0 || kind < 0 || kind > 3 || !src || !dst || nslabs <= 0 || count <= 0) return MSL_ERR_ARG;
+  GradReduceEntry e{src, dst, dst2, stride, kind, nslabs, count, first_block, p0, p1, p2, 0};
+  ((GradReduceEntry*)host_table)[index] = e;
+  if (grad_reduce_few(kind, nslabs, count, stride) && ((uintptr_t)src % 16 == 0) && (kind != GR_SLAB_F32 || (uintptr_t)dst % 16 == 0))
+    return msl::cdiv(count, 1024);
+  ((GradReduceEntry*)host_table)[index].pad = 1;  // force the many-slab form (unaligned pointers)
+  return msl::cdiv(count, 32);
+}
+
+int msl_grad_reduce_batch(const void* table, int n_entries, int total_blocks, void* stream) {
+  if (!table || n_entries <= 0 || n_entries > 64 || total_blocks <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(grad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const GradReduceEntry*)table, n_entries);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -11,6 +11,7 @@
 //   bwd-wgt : dW[Cout x Cin] = sum_{n,s} dY[co,s] * A[ci,s]      (split over s, fixed-order slab reduction)
 #include "common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -656,6 +657,128 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// bwd-weight, wave-autonomous form (the default for S % 32 == 0 and Cin % 32 == 0, Cout % 32 == 0).
+//   dW[co][ci] = sum over positions of dY[co][p] * A[ci][p]:  positions are the MFMA K dimension.
+// A wave owns a (32*MT) x 32 tile of dW and walks 32-position chunks of its workgroup's position range; both MFMA
+// operands come straight from global memory into registers - lane (h, c) loads the 16 consecutive positions
+// p0 + 16h .. p0 + 16h + 15 of row c (four 16-byte loads per operand row; a chunk of a row is exactly one 128-byte line),
+// and MFMA step kk contracts positions p0 + kk (lanes 0-31) and p0 + 16 + kk (lanes 32-63).  The next chunk's loads
+// are in flight during this chunk's MFMAs (two register sets); no LDS and no barrier in the loop, so the 4 waves of a
+// workgroup drift apart and loads / MFMAs of different waves overlap.  The 4 private tiles meet in LDS once at the
+// end (fixed order 0..3); the workgroup then stores its sum either straight into dW (the whole position range in one
+// workgroup: tail layers, 256 positions) or into its slab of a [nslabs][Cout][Cin] workspace that the batched gradient
+// reduction (optim.hip: grad_reduce_batch_kernel) sums in slab order.  No float atomics: run-to-run bit-identical.
+template <int MT, bool AFFINE>
+__global__ __launch_bounds__(256) void pw_bww_wave_kernel(const float* __restrict__ dY, const float* __restrict__ Z,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, float* __restrict__ out,
+                                                          int Cout, int Cin, int S, int chunks_per_img, int total_chunks,
+                                                          int chunks_per_block) {
+  __shared__ __align__(16) float red[4 * MT * 1024];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+  const int ks = blockIdx.x;
+  const int tiles_n = Cin / 32;
+  const int tm = blockIdx.y / tiles_n, tn = blockIdx.y % tiles_n;
+  const int m0 = tm * 32 * MT, n0 = tn * 32;
+  const int ch_lo = ks * chunks_per_block, ch_hi = min(total_chunks, ch_lo + chunks_per_block);
+  const int mine = max(0, (ch_hi - ch_lo - wv + 3) / 4);  // chunks ch_lo + wv, + 4, ...
+
+  float sc = 1.f, sh = 0.f;
+  if (AFFINE) {
+    sc = in_scale[n0 + c];
+    sh = in_shift[n0 + c];
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x16){0};
+
+  float4 a0[MT][4], b0[4], a1[MT][4], b1[4];
+  // chunk index -> row pointers; indices past the range are clamped (their products are skipped below)
+  auto issue = [&](int i, float4 (&a)[MT][4], float4 (&b)[4]) {
+    const int ch = min(ch_lo + wv + 4 * i, total_chunks - 1);
+    const int n = ch / chunks_per_img, s0 = (ch - n * chunks_per_img) * 32 + 16 * h;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const float4* p = reinterpret_cast<const float4*>(dY + ((size_t)n * Cout + m0 + mt * 32 + c) * S + s0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[mt][j] = p[j];
+    }
+    const float4* q = reinterpret_cast<const float4*>(Z + ((size_t)n * Cin + n0 + c) * S + s0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = q[j];
+  };
+  auto mac = [&](float4 (&a)[MT][4], float4 (&b)[4]) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float bv[4] = {b[j].x, b[j].y, b[j].z, b[j].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float x = AFFINE ? msl::act(bv[e], sc, sh) : bv[e];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float av = e == 0 ? a[mt][j].x : e == 1 ? a[mt][j].y : e == 2 ? a[mt][j].z : a[mt][j].w;
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, x, acc[mt], 0, 0, 0);
+        }
+      }
+    }
+  };
+
+  if (mine > 0) issue(0, a0, b0);
+#pragma unroll 1
+  for (int i = 0; i < mine; i += 2) {
+    issue(i + 1, a1, b1);  // clamped: always a valid address
+    __builtin_amdgcn_sched_barrier(0);
+    mac(a0, b0);
+    if (i + 1 < mine) {
+      issue(i + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mac(a1, b1);
+    }
+  }
+
+  // the 4 waves' tiles meet in LDS: red[wv][mt][row][col]
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wv * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c] = acc[mt][r];
+  __syncthreads();
+  float* dst = out + (size_t)ks * Cout * Cin;
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int q4 = threadIdx.x + e * 256;        // float4 index inside the (32*MT) x 32 tile
+    const int row = q4 >> 3, col = (q4 & 7) * 4;  // row = mt*32 + r
+    float4 v = *reinterpret_cast<const float4*>(&red[(0 * MT * 32 + row) * 32 + col]);
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const float4 t = *reinterpret_cast<const float4*>(&red[(w2 * MT * 32 + row) * 32 + col]);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    *reinterpret_cast<float4*>(dst + (size_t)(m0 + row) * Cin + n0 + col) = v;
+  }
+}
+
+struct BwwWavePlan {
+  int mt, tiles, chunks_per_img, total_chunks, ksplit, chunks_per_block;
+};
+
+// Supported: whole 32-position chunks and 32-channel tiles.  nslabs == 1 -> the kernel writes dW itself.
+static inline bool bww_wave_plan(int N, int Cin, int Cout, int S, BwwWavePlan& p) {
+  static const int off = getenv("MSL_PW_BWW_WAVE") ? atoi(getenv("MSL_PW_BWW_WAVE")) : 1;
+  if (!off || S % 32 != 0 || Cin % 32 != 0 || Cout % 32 != 0) return false;
+  p.mt = (Cout % 64 == 0) ? 2 : 1;
+  p.tiles = (Cout / (32 * p.mt)) * (Cin / 32);
+  p.chunks_per_img = S / 32;
+  p.total_chunks = N * p.chunks_per_img;
+  // position split: about one workgroup per CU in total, at least 8 chunks (2 per wave) each - every split costs a
+  // Cout x Cin slab written and read back
+  static const int target = getenv("MSL_PW_BWW_WGS") ? atoi(getenv("MSL_PW_BWW_WGS")) : 256;
+  int ks = std::max(1, std::min(target / std::max(1, p.tiles), p.total_chunks / 8));
+  p.chunks_per_block = msl::cdiv(p.total_chunks, ks);
+  p.ksplit = msl::cdiv(p.total_chunks, p.chunks_per_block);
+  return true;
+}
+
 // out[i] = sum_k slabs[k][i], k ascending (fixed order)
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ out,
                                                           int count, int nslabs) {
@@ -794,27 +917,65 @@ int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
 }
 
 size_t msl_pwconv_bwd_weight_workspace_bytes(int N, int Cin, int Cout, int S) {
+  BwwWavePlan wp;
+  if (bww_wave_plan(N, Cin, Cout, S, wp)) return (size_t)wp.ksplit * Cout * Cin * sizeof(float);
   BwPlan p = bw_plan(N, Cin, Cout, S);
   return (size_t)p.ksplit * Cout * Cin * sizeof(float);
 }
 
-// dW (Cout,Cin) = sum_{n,s} dy[n,co,s] * relu(bn(z))[n,ci,s]
-int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale, const float* in_shift,
-                          float* dw, float* workspace, int N, int Cin, int Cout, int S, void* stream) {
-  if (N <= 0 || S <= 0 || Cin % 32 != 0 || Cout % 64 != 0) return MSL_ERR_ARG;
-  BwPlan p = bw_plan(N, Cin, Cout, S);
+// Number of [Cout][Cin] slabs msl_pwconv_bwd_weight_slabs writes for this shape (1: the result itself).
+int msl_pwconv_bwd_weight_nslabs(int N, int Cin, int Cout, int S) {
+  BwwWavePlan wp;
+  if (bww_wave_plan(N, Cin, Cout, S, wp)) return wp.ksplit;
+  return bw_plan(N, Cin, Cout, S).ksplit;
+}
+
+// Partial weight gradients: out = [nslabs][Cout][Cin] (nslabs from msl_pwconv_bwd_weight_nslabs); their sum in slab
+// order is dW.  With nslabs == 1 `out` may be the gradient tensor itself.
+int msl_pwconv_bwd_weight_slabs(const float* dy, const float* z, const float* in_scale, const float* in_shift,
+                                float* out, int N, int Cin, int Cout, int S, void* stream) {
+  if (N <= 0 || S <= 0 || Cin % 32 != 0 || Cout % 32 != 0) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  BwwWavePlan wp;
+  if (bww_wave_plan(N, Cin, Cout, S, wp)) {
+    dim3 grid(wp.ksplit, wp.tiles);
+#define MSL_BWW(MT_, A_)                                                                                          \
+  hipLaunchKernelGGL((pw_bww_wave_kernel<MT_, A_>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, \
+                     S, wp.chunks_per_img, wp.total_chunks, wp.chunks_per_block)
+    if (wp.mt == 2) {
+      if (in_scale) MSL_BWW(2, true); else MSL_BWW(2, false);
+    } else {
+      if (in_scale) MSL_BWW(1, true); else MSL_BWW(1, false);
+    }
+#undef MSL_BWW
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
+  if (Cout % 64 != 0) return MSL_ERR_ARG;
+  BwPlan p = bw_plan(N, Cin, Cout, S);
   dim3 grid(p.ksplit, (Cout / 64) * (Cin / p.bnn));
   if (p.bnn == 64) {
-    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<64, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
-    else hipLaunchKernelGGL((pw_bwd_weight_kernel<64, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<64, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    else hipLaunchKernelGGL((pw_bwd_weight_kernel<64, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
   } else {
-    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<32, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
-    else hipLaunchKernelGGL((pw_bwd_weight_kernel<32, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, workspace, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<32, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    else hipLaunchKernelGGL((pw_bwd_weight_kernel<32, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
   }
   MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// dW (Cout,Cin) = sum_{n,s} dy[n,co,s] * relu(bn(z))[n,ci,s]   (stand-alone form: partial slabs + their reduction; the
+// training step uses msl_pwconv_bwd_weight_slabs and reduces the slabs of every layer in one msl_grad_reduce_batch)
+int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale, const float* in_shift,
+                          float* dw, float* workspace, int N, int Cin, int Cout, int S, void* stream) {
+  const int nslabs = msl_pwconv_bwd_weight_nslabs(N, Cin, Cout, S);
+  if (nslabs == 1) return msl_pwconv_bwd_weight_slabs(dy, z, in_scale, in_shift, dw, N, Cin, Cout, S, stream);
+  const int rc = msl_pwconv_bwd_weight_slabs(dy, z, in_scale, in_shift, workspace, N, Cin, Cout, S, stream);
+  if (rc != MSL_OK) return rc;
   const int count = Cout * Cin;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(msl::cdiv(count, 32)), dim3(256), 0, st, workspace, dw, count, p.ksplit);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(msl::cdiv(count, 32)), dim3(256), 0, (hipStream_t)stream, workspace, dw,
+                     count, nslabs);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

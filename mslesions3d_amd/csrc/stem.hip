@@ -704,7 +704,15 @@ size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin) {
   return (size_t)STEM_BW_BLOCKS * 32 * 32 * NT * sizeof(float);
 }
 
-// dw (32,Cin,3,3,3) = correlation of dy (N,32,OD,OH,OW) with x (N,Cin,D,H,W)
+// number of [32][32*NT] slabs the stem weight-gradient kernels leave in `workspace` (NT = ceil(Cin*27 / 32))
+int msl_stem_conv_bwd_weight_nslabs(int N, int D, int H, int W, int sd, int sh, int sw) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || sd < 1 || sh < 1 || sw < 1) return MSL_ERR_ARG;
+  const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
+  return std::min(STEM_BW_BLOCKS, msl::cdiv(N * OD * OH * msl::cdiv(OW, 64), 4));
+}
+
+// dw (32,Cin,3,3,3) = correlation of dy (N,32,OD,OH,OW) with x (N,Cin,D,H,W).  For all three forms: dw == NULL leaves
+// the partial slabs in `workspace` (deferred reduction, msl_grad_reduce_batch kind 2).
 static int stem_bww_impl(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
                          int sd, int sh, int sw, const float* yraw, const float* bnv, const float* w1, void* stream);
 
@@ -776,6 +784,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
 #undef MSL_STEM_BW
 #undef MSL_STEM_BW1
   MSL_LAUNCH_CHECK();
+  if (!dw) return MSL_OK;  // deferred: the caller folds the slabs with msl_grad_reduce_batch (kind 2)
   const int K = Cin * 27;
   hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw, K,
                      NT, nblocks);

@@ -181,20 +181,24 @@ class Plan:
             self.g_z = [None] + [torch.empty_like(t) for t in self.z[1:]]
             mt16 = 16 * ((12 + 2 * ncls + 15) // 16)
             self.dO = {f: torch.zeros((N, mt16) + tuple(d + 2 for d in self.dims[f]), **f32) for f in self.feat_ids}
-            ws = L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"])
+            self.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
+            # Deferred gradient reduction (Engine._grad_reduce): every weight-gradient kernel leaves its partial sums in a
+            # buffer of ITS OWN (they all stay live until the one batched reduction in front of the optimiser):
+            #   pw_slabs[i]  fp32 [nslabs][Cout][Cin] (None: the kernel covers the whole position range and writes dW itself)
+            #   dw_part[i]   fp64 [Cin*27][NP]
+            self.pw_nslabs, self.pw_slabs, self.dw_np, self.dw_part = [0], [None], [0], [None]
             for i in range(1, len(specs)):
                 D, H, W = self.dims[i]
-                ws = max(ws, L.msl_pwconv_bwd_weight_workspace_bytes(N, specs[i]["cin"], specs[i]["cout"], D * H * W))
-            self.ws = torch.empty(max(ws // 4, 1), **f32)
-            # private scratch of the weight-gradient launches (they overlap the main stream's kernels, and pl.partials may
-            # hold BatchNorm reduce partials that are consumed only after the weight gradients of the layer were enqueued)
-            self.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
-            self.partials_w = torch.empty_like(self.partials)
-            # second set: odd blocks' weight gradients may run on the heads stream beside the even blocks' (Engine.split_wgrad)
-            self.ws_b = torch.empty_like(self.ws)
-            self.partials_w_b = torch.empty_like(self.partials)
-            self.ws_c = torch.empty_like(self.ws)       # third set: MSL_WGRAD_SPLIT=2 (a stream of its own)
-            self.partials_w_c = torch.empty_like(self.partials)
+                pd, ph, pw = self.dims[i - 1]
+                ns = L.msl_pwconv_bwd_weight_nslabs(N, specs[i]["cin"], specs[i]["cout"], D * H * W)
+                self.pw_nslabs.append(ns)
+                self.pw_slabs.append(torch.empty(ns * specs[i]["cin"] * specs[i]["cout"], **f32) if ns > 1 else None)
+                npd = L.msl_dwconv_bwd_weight_num_partials(N, specs[i]["cin"], pd, ph, pw, specs[i]["stride"][0])
+                self.dw_np.append(npd)
+                self.dw_part.append(torch.empty(specs[i]["cin"] * 27 * npd, dtype=torch.float64, device=device))
+            self.head_nslabs = {f: L.msl_head_conv_bwd_weight_nslabs(N, specs[f]["cout"], *self.dims[f]) for f in self.feat_ids}
+            self.stem_nslabs = L.msl_stem_conv_bwd_weight_nslabs(N, *self.in_dims, *specs[0]["stride"])
+            self.grad_tables = {}
             # fused stem backward (block 1 is a stride-2 depthwise layer fed by a 32-channel stem that is not a head
             # feature): its dL/d(stem activation) is never materialised (Engine.backward)
             self.fused_stem_np = -1
@@ -232,10 +236,13 @@ class Engine:
         self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
         self.extra = {}
         self.early_pw_bww = os.environ.get("MSL_EARLY_PW_BWW", "0") == "1"
+        # the weight gradients of block i are enqueued after the chain launches of block i - wgrad_lag (host enqueue order
+        # only; on the device they wait for their events): a larger lag keeps the dependency chain's queue ahead of the GPU
+        self.wgrad_lag = int(os.environ.get("MSL_WGRAD_LAG", "1"))
         e = os.environ.get("MSL_WGRAD_ON_HEADS")
         self.wgrad_on_heads = None if e is None else {int(v) for v in e.split(",") if v.strip()}
-        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "32"))
-        self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", str(self.fold_np_max)))
+        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "65536"))
+        self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", "32"))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
         self.side = {}
         self.arena = None
@@ -577,8 +584,8 @@ class Engine:
                 _lib.call("msl_event_record", data_done_event, st, tag="event")
         if not weight:
             return
-        self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), ptr(gv[pre[0] + ".weight"]),
-                ptr(gv[pre[1] + ".weight"]), ptr(gv[pre[0] + ".bias"]), ptr(gv[pre[1] + ".bias"]),
+        # weight and bias slabs stay in head_ws[f] (folded by the batched gradient reduction)
+        self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), None, None, None, None,
                 ptr(pl.head_ws[f]), pl.N, C, D, H, W, ncls, st)
 
     def backward(self, pl, dlocs, dscores, on_bucket_ready=None):
@@ -603,6 +610,9 @@ class Engine:
         dlocs = dlocs.contiguous()
         dscores = dscores.contiguous()
         wanted = getattr(on_bucket_ready, "stages", None)
+        # data parallel: the partial sums of a gradient bucket are folded when the bucket's last stage has been enqueued
+        # (stage -> parameter names); single process: one reduction at the very end
+        groups = self._bucket_groups(on_bucket_ready) if wanted else {}
 
         def report(stage, join_heads=False):
             if on_bucket_ready is None or (wanted is not None and stage not in wanted):
@@ -634,6 +644,10 @@ class Engine:
                     self._fork(pl, f"bucket_h{stage}", stH, st)
                 if stX != stW:
                     self._fork(pl, f"bucket_x{stage}", stX, st)
+            if stage in groups:  # fold the partial sums of this stage's buckets where their exchange will run
+                comm2 = getattr(on_bucket_ready, "comm_stream", None)
+                on_main = comm2 is None or (stage == 0 and getattr(on_bucket_ready, "final_on_main", False))
+                self._grad_reduce(pl, stage, groups[stage], st if on_main else comm2.cuda_stream)
             self._hook(on_bucket_ready, stage)
 
         # heads: the last scale feeds the chain immediately (main stream); the earlier scales are only needed when
@@ -645,6 +659,7 @@ class Engine:
         L = _lib.load()
         pre_np = None  # set when the producer of the next activation gradient also produced its BatchNorm partials
         pending = []  # side-stream launches, issued one layer late so that the chain's launches always go first
+        sinks = []    # (layer, closure) of the weight-gradient launches still to be issued
         for f in pl.feat_ids:  # the chain's own scale first: its data gradient starts the backward chain
             if f not in side_feats:
                 if ms:
@@ -710,37 +725,39 @@ class Engine:
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
             def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red,
                        ev_dy=ev_dy):
-                # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there (own scratch)
-                sets = [(stW, pl.ws, pl.partials_w), (stH, pl.ws_b, pl.partials_w_b), (stX, pl.ws_c, pl.partials_w_c)]
-                sX, wsX, pwX = sets[i % (self.split_wgrad + 1)] if ms else sets[0]
+                # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there
+                streams = [stW, stH, stX]
+                sX = streams[i % (self.split_wgrad + 1)] if ms else st
                 if ms and self.wgrad_on_heads is not None:  # experiment knob: explicit list of blocks for the heads stream
-                    sX, wsX, pwX = sets[1] if i in self.wgrad_on_heads else sets[0]
+                    sX = stH if i in self.wgrad_on_heads else stW
                 if ms:  # the pointwise gradient needs dL/dy_i, the depthwise one dL/dz_i
                     self._wait(sX, ev_dy if ev_dy is not None else ev_dz)
-                self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
-                        ptr(pl.bn_z[i][1]), ptr(gv[name + ".conv2.weight"]), ptr(wsX), N, sp["cin"], sp["cout"], S, sX)
+                # partial sums only: slabs / fp64 partials stay in this layer's own buffers until Engine._grad_reduce
+                out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
+                self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
+                        ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, sX)
                 if ms and ev_dy is not None:
                     self._wait(sX, ev_dz)
                 if fused_stem:
-                    if ms:
-                        self._wait(sX, ev_red)
-                    self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_finalize", ptr(pl.partials_wf), pl.fused_stem_np,
-                            ptr(gv[name + ".conv1.weight"]), sp["cin"], sX)
-                    return
+                    return  # its partials came with the fused stem backward pass (pl.partials_wf)
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
-                        ptr(pl.bn_y[i - 1][1]), ptr(gv[name + ".conv1.weight"]), ptr(pwX),  # never pl.partials: it may hold the next BatchNorm's reduce partials
-                        N, sp["cin"], pd, ph, pw, s, sX)
+                        ptr(pl.bn_y[i - 1][1]), None, ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, sX)
 
-            # issue what the previous layer left for the side streams, then queue this layer's
+            # issue what earlier layers left for the side streams (the head gradients the chain waits for: one layer late;
+            # the weight gradients, which nothing in the step waits for: wgrad_lag layers late), then queue this layer's
             for fn in pending:
                 fn()
-            pending = [wgrads] if ms else []
-            if not ms:
+            pending = []
+            if ms:
+                sinks.append((i, wgrads))
+                while sinks and sinks[0][0] >= i + self.wgrad_lag:
+                    sinks.pop(0)[1]()
+            else:
                 wgrads()
             if wanted is not None and i in wanted:
-                for fn in pending:
+                for _, fn in sinks:
                     fn()
-                pending = []
+                sinks = []
             report(i, join_heads=self.split_wgrad > 0)
         # stem
         od, oh, ow = pl.dims[0]
@@ -754,25 +771,94 @@ class Engine:
                          apply=False, coef=fused)
             if fused:
                 self._k("stem_bww", "msl_stem_conv_bwd_weight_fused", ptr(pl.g_z[1]), ptr(pl.w1_taps_t), ptr(pl.y[0]),
-                        ptr(pl.bn_y[0]), ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N,
+                        ptr(pl.bn_y[0]), ptr(pl.saved_input), None, ptr(pl.ws_stem), N,
                         specs[0]["cin"], D, H, W, sd, sh, sw, st)
             else:
                 self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(pl.bn_y[0]),
-                        ptr(pl.saved_input), ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W,
-                        sd, sh, sw, st)
+                        ptr(pl.saved_input), None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         else:
             self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st,
                          pre_np=pre_np)
             self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input),
-                    ptr(gv["base.features.0.0.weight"]), ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
+                    None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         for fn in pending:
+            fn()
+        for _, fn in sinks:
             fn()
         if ms:  # every gradient is complete once the side streams have been joined
             self._fork(pl, "bwd_join_w", stW, st)
             self._fork(pl, "bwd_join_h", stH, st)
             if stX != stW:
                 self._fork(pl, "bwd_join_x", stX, st)
+        if not groups:  # single process: ONE reduction launch for every layer's partial sums, right in front of the optimiser
+            self._grad_reduce(pl, "all", None, st)
         report(0)
+
+    def _bucket_groups(self, reducer):
+        """stage -> set of parameter names whose gradient bucket completes at that stage (GradBucketReducer layout)."""
+        groups = {}
+        for stage, buckets in reducer.trigger.items():
+            names = set()
+            for k in buckets:
+                lo, hi = reducer.ranges[k]
+                names |= {n for n, (off, cnt) in self.arena.offsets.items() if n not in self.arena.no_grad_names and lo <= off < hi}
+            groups[stage] = names
+        return groups
+
+    def _grad_reduce(self, pl, key, names, st):
+        """One launch that folds the partial weight-gradient sums (pointwise slabs, depthwise fp64 partials, head and stem
+        slabs) of the parameters in ``names`` (None: all) into the gradient arena (table built once per plan and key)."""
+        import ctypes
+        L = _lib.load()
+        ent = pl.grad_tables.get(key)
+        if ent is None:
+            gv = self.arena.grad_views
+            specs, m = self.layer_specs, self.model
+            ncls = m.n_classes
+            rows = []  # (kind, src, dst, dst2, nslabs, count, stride, p0, p1, p2)
+            want = lambda n: names is None or n in names
+            for k, f in enumerate(pl.feat_ids):
+                lw, cw = f"pred_convs.loc_convs.{k}.weight", f"pred_convs.cl_convs.{k}.weight"
+                if want(lw) or want(cw):
+                    if not (want(lw) and want(cw)):
+                        raise RuntimeError("a gradient bucket boundary separates the two head convolutions of one scale")
+                    C = specs[f]["cout"]
+                    mt = (12 + 2 * ncls + 15) // 16
+                    slab = (C // 16) * 27 * mt * 256
+                    ns = pl.head_nslabs[f]
+                    rows.append((3, pl.head_ws[f], gv[lw], gv[cw], ns, slab, slab, C, mt, 12 + 2 * ncls))
+                    bias = pl.head_ws[f][ns * slab:]  # [ns][16*mt] row sums of dO: rows 0-11 loc, 12.. cls
+                    rows.append((0, bias, gv[lw[:-6] + "bias"], None, ns, 12, 16 * mt, 0, 0, 0))
+                    rows.append((0, bias[12:], gv[cw[:-6] + "bias"], None, ns, 2 * ncls, 16 * mt, 0, 0, 0))
+            fused = self.fuse_stem and pl.fused_stem_np > 0
+            for i in range(len(specs) - 1, 0, -1):
+                name = f"base.features.{i}"
+                cnt = specs[i]["cin"] * specs[i]["cout"]
+                if want(name + ".conv2.weight") and pl.pw_nslabs[i] > 1:
+                    rows.append((0, pl.pw_slabs[i], gv[name + ".conv2.weight"], None, pl.pw_nslabs[i], cnt, cnt, 0, 0, 0))
+                if want(name + ".conv1.weight"):
+                    if i == 1 and fused:
+                        rows.append((1, pl.partials_wf, gv[name + ".conv1.weight"], None, pl.fused_stem_np, specs[i]["cin"] * 27, 0, 0, 0, 0))
+                    else:
+                        rows.append((1, pl.dw_part[i], gv[name + ".conv1.weight"], None, pl.dw_np[i], specs[i]["cin"] * 27, 0, 0, 0, 0))
+            if want("base.features.0.0.weight"):
+                K = specs[0]["cin"] * 27
+                nt = (K + 31) // 32
+                rows.append((2, pl.ws_stem, gv["base.features.0.0.weight"], None, pl.stem_nslabs, 1024 * nt, 1024 * nt, K, nt, 0))
+            esz = L.msl_grad_reduce_entry_bytes()
+            host = (ctypes.c_ubyte * (esz * max(len(rows), 1)))()
+            first = 0
+            for k, (kind, src, dst, dst2, ns, cnt, stride, p0, p1, p2) in enumerate(rows):
+                nb = L.msl_grad_reduce_table_set(ctypes.addressof(host), k, first, kind, ptr(src), ptr(dst), ptr(dst2), ns, cnt,
+                                                 stride, p0, p1, p2)
+                if nb < 0:
+                    raise _lib.HipKernelError(f"msl_grad_reduce_table_set failed for entry {k} (kind {kind})")
+                first += nb
+            table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.arena.grad.device) if rows else None
+            ent = pl.grad_tables[key] = (table, len(rows), first)
+        table, n, blocks = ent
+        if n:
+            self._k(f"grad_reduce:{key}", "msl_grad_reduce_batch", ptr(table), n, blocks, st)
 
     def check_nan(self, pl):
         """One host sync: raise like ssd3d.py:258-261 if the forward produced NaN."""

@@ -20,10 +20,6 @@ from .ssd3d import MultiBoxLoss
 
 
 class FusedTrainer:
-    _GRAPH_MSG = ("HIP-graph capture of the training step (opt-in, MSL_USE_GRAPH=1 / use_graph) is not supported by the "
-                  "present multi-stream schedule: the capture ends with hipErrorStreamCaptureUnjoined and leaves the "
-                  "streams unusable; unset it (native launch-program replay is the measured-faster default)")
-
     def __init__(self, model, lr=None, n_buckets=3, process_group=None):
         self.model = model
         self.opt = FusedAdam(model, lr=model.lr if lr is None else lr, weight_decay=0.0005)
@@ -31,9 +27,10 @@ class FusedTrainer:
         self.n_buckets, self.group = n_buckets, process_group
         self.reducer = None
         self.last_plan = None
-        self.use_programs = True   # replay recorded launch programs after the first step on a set of buffers
-        self.use_graph = os.environ.get("MSL_USE_GRAPH", "0") == "1"  # optional HIP-graph capture of the program (measured slower than replay on ROCm 7.2:
-                                   # 1.61 vs 1.28 ms/step — the multi-stream overlap is lost inside the graph)
+        # Replay recorded launch programs after the first step on a set of buffers (natively, two issuing threads).
+        # A HIP-graph capture of the same program works but replays at 1.76 ms/step against 1.01 ms (ROCm 7.2, round 2:
+        # hipGraphLaunch of the 127-node three-stream graph alone holds the host for 1.1 ms), so there is no graph path.
+        self.use_programs = True
         self._programs = collections.OrderedDict()  # LRU, at most max_programs entries (each pins its input tensors)
         self.max_programs = 16
         self._staging = {}         # (image shape, target capacity) -> persistent input buffers (see _stage)
@@ -156,7 +153,7 @@ class FusedTrainer:
                     prog = _lib.stop_recording() if self.use_programs else None
                 if self.use_programs:
                     # keep the tensors the program points at alive for as long as the program exists
-                    self._programs[key] = {"prog": prog, "plan": pl, "state": st, "graph": None,
+                    self._programs[key] = {"prog": prog, "plan": pl, "state": st,
                                            "keep": (images, gt_boxes, gt_labels, obj_off)}
                     while len(self._programs) > self.max_programs:
                         self._programs.popitem(last=False)
@@ -165,35 +162,15 @@ class FusedTrainer:
                 pl.generation += 1
                 pl.saved_input, pl.trained_mode = images, True
                 self.opt.prepare_step(grad_scale=1.0 / red.world)
-                graph_ok = self.use_graph and not red.active
-                parts = None
-                if eng.prof is not None and graph_ok:
-                    # time the tagged launches individually, everything before / after them stays a captured graph
-                    tags = frozenset(eng.prof_tags)
-                    parts = entry.setdefault("segments", {}).get(tags)
-                    if parts is None:
-                        try:
-                            parts = entry["segments"][tags] = _lib.capture_segments(prog, stream, tags)
-                        except _lib.HipKernelError as e:
-                            raise _lib.HipKernelError(self._GRAPH_MSG) from e
-                if parts is not None:
-                    _lib.run_segments(parts, stream, eng.prof, lambda: torch.cuda.Event(enable_timing=True))
-                elif eng.prof is not None:
+                if eng.prof is not None:
                     tags = frozenset(eng.prof_tags)
                     segs = entry.setdefault("native_timed", {}).get(tags)
                     if segs is None:
-                        segs = entry["native_timed"][tags] = _lib.compile_program(prog, tags)
+                        segs = entry["native_timed"][tags] = _lib.compile_program(prog, tags, stream, dev.index or 0)
                     _lib.replay_native(segs, eng.prof)
-                elif graph_ok:
-                    if entry["graph"] is None:
-                        try:
-                            entry["graph"] = _lib.capture_graph(prog, stream)
-                        except _lib.HipKernelError as e:
-                            raise _lib.HipKernelError(self._GRAPH_MSG) from e
-                    _lib.check(_lib.load().msl_graph_launch(entry["graph"], stream), "msl_graph_launch")
                 else:
                     if "native" not in entry:
-                        entry["native"] = _lib.compile_program(prog)
+                        entry["native"] = _lib.compile_program(prog, (), stream, dev.index or 0)
                     _lib.replay_native(entry["native"])
         caller.wait_stream(self._stream)
         self.last_plan = pl

@@ -257,6 +257,8 @@ def main():
             ("network_c64", lambda: gen_network(ref_ssd3d, "c64", 2, 1, (64, 64, 64), 7)),
             ("network_a128", lambda: gen_network(ref_ssd3d, "a128", 4, 1, (128, 128, 128), 61)),
             ("network_a2_2ch64", lambda: gen_network(ref_ssd3d, "a2_2ch64", 2, 2, (64, 64, 64), 7)),
+            # BASELINE configs[4]: multi-modal 2-channel (T1 + FLAIR) 128^3, batch 4
+            ("network_a2_2ch128", lambda: gen_network(ref_ssd3d, "a2_2ch128", 4, 2, (128, 128, 128), 61)),
             ("network_noncube", lambda: gen_network(ref_ssd3d, "noncube", 2, 1, (48, 64, 64), 7)),
             ("detect", lambda: gen_detect(ref_ssd3d)), ("map", lambda: gen_map(ref_utils))]
     for name, job in jobs:

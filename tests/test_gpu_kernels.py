@@ -295,7 +295,11 @@ def _fused_stem_case(cin, dims):
 
 # ------------------------------------------------------------------------------------------------- pointwise
 @pytest.mark.parametrize("N,Cin,Cout,S", [(2, 32, 64, 1000), (1, 64, 128, 64), (2, 128, 128, 130), (1, 512, 512, 8),
-                                          (1, 256, 512, 27)])
+                                          (1, 256, 512, 27),
+                                          # S % 32 == 0: the wave-autonomous weight-gradient kernel (whole range in one
+                                          # workgroup / split over slabs / odd chunk counts per wave / 32-row tiles)
+                                          (4, 512, 512, 64), (4, 256, 512, 64), (2, 128, 256, 512), (3, 64, 128, 4096),
+                                          (2, 32, 64, 32768), (1, 32, 96, 96), (1, 64, 32, 32), (3, 96, 160, 1120)])
 def test_pw_fwd_bwd(N, Cin, Cout, S):
     L = _lib.load()
     z = rnd(N, Cin, S, seed=10)
@@ -321,7 +325,84 @@ def test_pw_fwd_bwd(N, Cin, Cout, S):
     dw = torch.full((Cout, Cin), float("nan"), device=DEV)
     _lib.call("msl_pwconv_bwd_weight", ptr(K(dy)), ptr(K(z)), ptr(K(sc)), ptr(K(sh)), ptr(dw), ptr(ws),
               N, Cin, Cout, S, st())
-    close(dw, w.grad, 1e-4, 1e-4, "pw bwd weight")
+    atol = max(1e-4, 5e-6 * float(w.grad.abs().max()))  # long sums (up to 65 536 products) cancel: error scales with max |dW|
+    close(dw, w.grad, 1e-4, atol, "pw bwd weight")
+    if Cin % 32 == 0 and Cout % 32 == 0 and (Cout % 64 == 0 or S % 32 == 0):
+        # the slab form the training step uses + the batched reduction (kind 0); bit-identical to the stand-alone entry
+        ns = L.msl_pwconv_bwd_weight_nslabs(N, Cin, Cout, S)
+        slabs = torch.full((ns, Cout, Cin), float("nan"), device=DEV)
+        _lib.call("msl_pwconv_bwd_weight_slabs", ptr(K(dy)), ptr(K(z)), ptr(K(sc)), ptr(K(sh)), ptr(slabs), N, Cin, Cout, S, st())
+        if ns == 1:
+            assert torch.equal(slabs[0], dw)
+        else:
+            out = torch.full((Cout, Cin), float("nan"), device=DEV)
+            grad_reduce([(0, slabs, out, None, ns, Cout * Cin, Cout * Cin, 0, 0, 0)])
+            close(out, dw, 1e-5, atol, "batched slab reduction vs the stand-alone one (different, fixed, summation orders)")
+            out2 = torch.full((Cout, Cin), float("nan"), device=DEV)
+            grad_reduce([(0, slabs, out2, None, ns, Cout * Cin, Cout * Cin, 0, 0, 0)])
+            assert torch.equal(out, out2), "the reduction must be run-to-run bit-identical"
+        dw2 = torch.full((Cout, Cin), float("nan"), device=DEV)  # without the input affine
+        _lib.call("msl_pwconv_bwd_weight", ptr(K(dy)), ptr(K(z)), None, None, ptr(dw2), ptr(ws), N, Cin, Cout, S, st())
+        close(dw2, torch.einsum("nos,ncs->oc", dy.double(), z.double()).float(), 1e-4, atol, "pw bwd weight, no affine")
+
+
+def grad_reduce(rows):
+    """rows of (kind, src, dst, dst2, nslabs, count, stride, p0, p1, p2) -> one msl_grad_reduce_batch launch."""
+    import ctypes
+    L = _lib.load()
+    esz = L.msl_grad_reduce_entry_bytes()
+    host = (ctypes.c_ubyte * (esz * len(rows)))()
+    first = 0
+    for k, (kind, src, dst, dst2, ns, cnt, stride, p0, p1, p2) in enumerate(rows):
+        nb = L.msl_grad_reduce_table_set(ctypes.addressof(host), k, first, kind, ptr(src), ptr(dst), ptr(dst2), ns, cnt, stride,
+                                         p0, p1, p2)
+        assert nb in ((cnt + 31) // 32, (cnt + 1023) // 1024)
+        first += nb
+    table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(DEV)
+    _lib.call("msl_grad_reduce_batch", ptr(table), len(rows), first, st())
+    torch.cuda.synchronize()
+
+
+def test_grad_reduce_batch_all_kinds_in_one_launch():
+    """The batched gradient reduction against plain sums: fp32 slabs, fp64 partials, the padded stem image and the head
+    slab layout, several entries (ragged counts, 1..70 slabs) in ONE launch; canaries around every destination."""
+    g = torch.Generator().manual_seed(5)
+    rows, checks = [], []
+
+    def dst(n):
+        t = torch.full((n + 64,), float("nan"), device=DEV)
+        return t, t[32:32 + n]
+
+    for ns, cnt in ((1, 5), (7, 1000), (70, 333), (64, 2048), (3, 4096), (16, 1028), (9, 12)):  # kind 0
+        pad = 4 if cnt % 8 == 0 else 3  # stride > count; multiples of 4 take the few-slab vector form when ns <= 16
+        src = torch.randn((ns, cnt + pad), generator=g).to(DEV)
+        full, view = dst(cnt)
+        rows.append((0, src, view, None, ns, cnt, cnt + pad, 0, 0, 0))
+        checks.append((full, view, src[:, :cnt].double().sum(0).float(), 1e-5))
+    for NP, cnt in ((1, 27), (33, 864), (300, 100)):  # kind 1: [count][NP] fp64
+        src = torch.randn((cnt, NP), generator=g, dtype=torch.float64).to(DEV)
+        full, view = dst(cnt)
+        rows.append((1, src, view, None, NP, cnt, 0, 0, 0, 0))
+        checks.append((full, view, src.sum(1).float(), 1e-7))
+    for cin in (1, 2):  # kind 2: stem image [32][32*NT] -> [32][K]
+        Kk, NT = cin * 27, (cin * 27 + 31) // 32
+        src = torch.randn((9, 32, 32 * NT), generator=g).to(DEV)
+        full, view = dst(32 * Kk)
+        rows.append((2, src, view, None, 9, 1024 * NT, 1024 * NT, Kk, NT, 0))
+        checks.append((full, view, src.double().sum(0)[:, :Kk].reshape(-1).float(), 1e-5))
+    C, ncls, ns = 32, 2, 5  # kind 3: head slabs [ns][C/16][27*MT][16 co][16 ci] -> loc (12,C,27) / cls (4,C,27)
+    src = torch.randn((ns, C // 16, 27, 16, 16), generator=g).to(DEV)
+    fl, vl = dst(12 * C * 27)
+    fc, vc = dst(2 * ncls * C * 27)
+    rows.append((3, src, vl, vc, ns, (C // 16) * 27 * 256, (C // 16) * 27 * 256, C, 1, 12 + 2 * ncls))
+    tot = src.double().sum(0)  # [ct][tap][co][cil]
+    w = tot.permute(2, 0, 3, 1).reshape(16, C, 27).float()  # [co][ci = ct*16 + cil][tap]
+    checks.append((fl, vl, w[:12].reshape(-1), 1e-5))
+    checks.append((fc, vc, w[12:16].reshape(-1), 1e-5))
+    grad_reduce(rows)
+    for full, view, ref, tol in checks:
+        close(view, ref, tol, tol, "grad reduce")
+        assert torch.isnan(full[:32]).all() and torch.isnan(full[32 + view.numel():]).all(), "wrote outside its range"
 
 
 # ------------------------------------------------------------------------------------------------- batch norm

@@ -177,7 +177,8 @@ def test_cpu_input_fails_loudly():
 
 # ------------------------------------------------------------------------------------------------- network
 @pytest.mark.parametrize("tag,n,cin,size,stride", [("c64", 2, 1, (64, 64, 64), 7), ("a2_2ch64", 2, 2, (64, 64, 64), 7),
-                                                    ("noncube", 2, 1, (48, 64, 64), 7), ("a128", 4, 1, (128, 128, 128), 61)])
+                                                    ("noncube", 2, 1, (48, 64, 64), 7), ("a128", 4, 1, (128, 128, 128), 61),
+                                                    ("a2_2ch128", 4, 2, (128, 128, 128), 61)])
 def test_network_forward_backward_golden(tag, n, cin, size, stride):
     g = golden(f"network_{tag}")
     m = hip_model(cin, size)
@@ -320,18 +321,85 @@ def test_replayed_launch_program_equals_eager_steps():
         bs, ls = detinit.make_gt(60 + k, n, size)
         batches.append((xs,) + MultiBoxLoss.pack_targets(bs, ls, torch.device(DEV)))
     results = []
-    for use_programs in (True, False):
+    for use_programs, resident in ((True, False), (True, True), (False, False)):
         m = hip_model(1, size, lr=1e-3)
         m.train()
         tr = FusedTrainer(m)
         tr.use_programs = use_programs
-        losses = [tr.step_packed(*batches[s % 2])["loss"] for s in range(6)]
-        if use_programs:
-            assert len(tr._programs) == 2
+        losses = [tr.step_packed(*batches[s % 2], resident=resident)["loss"] for s in range(6)]
+        if use_programs:  # staged inputs: one program on the persistent buffers; resident inputs: one per input set
+            assert len(tr._programs) == (2 if resident else 1)
         results.append((losses, torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone(),
                         m.state_dict()["base.features.3.bn2.running_var"].clone()))
-    assert results[0][0] == results[1][0]
-    assert torch.equal(results[0][1], results[1][1]) and torch.equal(results[0][2], results[1][2])
+    for other in results[1:]:
+        assert results[0][0] == other[0]
+        assert torch.equal(results[0][1], other[1]) and torch.equal(results[0][2], other[2])
+
+
+def test_training_loop_with_fresh_batches_replays_one_program():
+    """A real training loop hands over freshly allocated tensors every step (train.py): the trainer stages them into
+    persistent buffers, so ONE recorded launch program per (shape, target capacity) is replayed and neither the program
+    cache nor device memory grows (the round-1 leak: one pinned program per step)."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (64, 64, 64), 2
+    m = hip_model(1, size, lr=1e-3)
+    m.train()
+    tr = FusedTrainer(m)
+    ref = hip_model(1, size, lr=1e-3)
+    ref.train()
+    tr_ref = FusedTrainer(ref)
+    tr_ref.use_programs = False  # the Python-driven executor on the caller's own tensors
+    mem = []
+    for s in range(50):
+        xs = detinit.make_volume_batch(100 + s, n, 1, size).to(DEV)          # fresh allocations every step
+        bs, ls = detinit.make_gt(200 + s, n, size)                          # 2..? objects per image: T varies
+        out = tr.step(xs, bs, ls)
+        if s < 6:
+            exp = tr_ref.step(xs.clone(), bs, ls)
+            assert out["loss"] == exp["loss"], f"step {s}: staged replay differs from the eager step"
+        del xs
+        if s >= 30:  # every target-capacity bucket has been seen by now
+            mem.append(torch.cuda.memory_allocated())
+    assert len(tr._programs) <= 3, len(tr._programs)     # one per target-capacity bucket (8 / 16 / 32 rows)
+    assert max(mem) - min(mem) <= 1 << 20, (min(mem), max(mem))
+    # resident=True keeps the round-1 behaviour (programs keyed on the caller's tensors), LRU-bounded
+    tr.max_programs = 4
+    from mslesions3d_amd.ssd3d import MultiBoxLoss
+    for s in range(8):
+        xs = detinit.make_volume_batch(300 + s, n, 1, size).to(DEV)
+        bs, ls = detinit.make_gt(400 + s, n, size)
+        tr.step_packed(xs, *MultiBoxLoss.pack_targets(bs, ls, torch.device(DEV)), resident=True)
+    assert len(tr._programs) <= 4
+
+
+def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
+    """resume_from_checkpoint (train.py:185): weights + Adam moments / step count + scheduler phase are restored, so
+    save -> load -> step equals the uninterrupted run bitwise."""
+    from mslesions3d_amd.ssd3d import LSSD3D
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (64, 64, 64), 2
+    data = [(detinit.make_volume_batch(70 + s, n, 1, size).to(DEV),) + detinit.make_gt(80 + s, n, size) for s in range(5)]
+    a = hip_model(1, size, lr=1e-3)
+    a.train()
+    ta = FusedTrainer(a)
+    for s in range(3):
+        ta.step(*data[s])
+    path = str(tmp_path / "mid.ckpt")
+    a.current_epoch = 4
+    a.save_checkpoint(path, ta)
+    la = [ta.step(*data[s])["loss"] for s in (3, 4)]
+    b = LSSD3D.load_from_checkpoint(path).to(DEV)
+    b.train()
+    tb = FusedTrainer(b)
+    ck = LSSD3D.read_checkpoint(path)
+    tb.load_state_dict({"optimizer": ck["optimizer_states"][0], "scheduler": ck["lr_schedulers"][0]})
+    assert b.global_step == 3 and b.current_epoch == 4 and tb.opt.step_count == 3 and tb.sch.last_epoch == 3
+    lb = [tb.step(*data[s])["loss"] for s in (3, 4)]
+    assert la == lb
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert torch.equal(pa, pb), k
+    for (k, pa), (_, pb) in zip(a.named_buffers(), b.named_buffers()):
+        assert torch.equal(pa, pb), k
 
 
 def test_in_kernel_bn_fold_is_bit_identical():
@@ -459,12 +527,23 @@ def test_detect_objects_golden(name):
                                         return_prior_index=True)
     for i in range(c["n"]):
         assert np.array_equal(l[i].cpu().numpy(), g[f"{name}__labels_{i}"])
-        if c["quantized"] or name == "none_found":
-            # exact ties / no near-ties: the keep-list is decided by the stable order -> bit-exact
-            assert torch.equal(pi[i].cpu(), oi[i]), "keep-list (prior indices) must be bit-exact"
+        hs, os_ = s[i].cpu(), osc[i]
+        if c["quantized"] or name == "none_found" or (hs.shape == os_.shape and torch.equal(hs, os_)):
+            # exact ties / no near-ties, or GPU and oracle scores bit-equal: the keep-list INCLUDING ITS ORDER is decided by
+            # the stable-sort / first-index rules -> bit-exact
+            assert torch.equal(pi[i].cpu(), oi[i]), "keep-list (prior indices, order) must be bit-exact"
         else:
-            # exp() differs from the CPU libm in the last ulp, which may swap two near-equal scores
-            assert set(pi[i].cpu().tolist()) == set(oi[i].tolist())
+            # exp() differs from the CPU libm in the last ulp, which may swap two near-equal scores: same set, and every
+            # position whose prior index differs must sit on a score that is NOT bit-equal to the oracle's and lies within
+            # 2 ulp of its swap partner; the count is reported
+            hp, op = pi[i].cpu(), oi[i]
+            assert set(hp.tolist()) == set(op.tolist())
+            diff = (hp != op).nonzero().flatten().tolist()
+            for k in diff:
+                assert hs[k] != os_[k] or hs[k] == hs[op.tolist().index(int(hp[k]))], (name, i, k)
+                partner = op.tolist().index(int(hp[k]))
+                assert abs(float(os_[k]) - float(os_[partner])) <= 3 * np.spacing(np.float32(abs(float(os_[k])))), (name, i, k)
+            print(f"[detect {name} image {i}] keep-list positions that differ from the oracle's order: {len(diff)} of {len(hp)}")
         np.testing.assert_allclose(s[i].cpu().numpy(), g[f"{name}__scores_{i}"], rtol=1e-5, atol=1e-7)
         order_h = np.argsort(pi[i].cpu().numpy(), kind="stable")
         order_o = np.argsort(oi[i].numpy(), kind="stable")
