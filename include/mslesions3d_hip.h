@@ -164,7 +164,7 @@ int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int
                            int ncls, void* stream);
 size_t msl_head_bwd_weight_workspace_bytes(int N, int C, int D, int H, int W, int ncls);
 /* slabs msl_head_conv_bwd_weight leaves in `workspace`; dloc_w == NULL skips its own reduction (deferred: kind 3) */
-int msl_head_conv_bwd_weight_nslabs(int N, int C, int D, int H, int W);
+int msl_head_conv_bwd_weight_nslabs(int N, int C, int D, int H, int W, int ncls);
 int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dloc_w, float* dcl_w, float* dloc_b,
                              float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls,
                              void* stream);

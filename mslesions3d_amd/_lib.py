@@ -59,7 +59,7 @@ _SIGNATURES = {
     "msl_pwconv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I]),
     "msl_pwconv_bwd_weight_slabs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_stem_conv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I, _I, _I, _I]),
-    "msl_head_conv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I, _I]),
+    "msl_head_conv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_grad_reduce_entry_bytes": (_Z, []),
     "msl_grad_reduce_table_set": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _Q, _I, _I, _I]),
     "msl_grad_reduce_batch": (_I, [_P, _I, _I, _P]),

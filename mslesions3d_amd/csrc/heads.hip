@@ -13,6 +13,7 @@
 // small, channel-heavy scales) with a fixed-order reduction.
 #include "common.hpp"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -376,6 +377,343 @@ __global__ __launch_bounds__(64) void head_bias_reduce_kernel(const float* __res
   else dcl_b[co - 12] = s;
 }
 
+// =====================================================================================================================
+// LDS-staged forms of the three head kernels for the cubic power-of-two feature maps of the training configurations
+// (W = H in {4, 8, 16}, S % 64 == 0).  The register-fed kernels above issue one 4-byte gather per MFMA operand (1.5
+// vector-memory instructions per 16x16x4 MFMA): with four waves per CU that saturates the CU's L1 path (64 B/clk) at a
+// quarter of the MFMA rate.  Here a workgroup owns a block of 64 consecutive positions (four 16-position tiles, one per
+// wave); the zero-haloed input slab of the block and the packed weight fragments are staged ONCE per workgroup through
+// LDS with coalesced loads (prefetched into registers one chunk ahead), and every MFMA operand is a conflict-free
+// ds_read_b32 (128 B/clk/CU, no tag lookup).  Blocks: W = 16 -> 4 rows of a plane, W = 8 -> a plane, W = 4 -> 4 planes.
+// staging helpers: arrays by reference into force-inlined functions stay in registers (a lambda capturing them did not)
+template <int NA>
+__device__ __forceinline__ void head_ld_f4(f32x4 (&av)[NA], const f32x4* __restrict__ wp, int tid, int total) {
+#pragma unroll
+  for (int i = 0; i < NA; ++i) av[i] = wp[min(tid + 256 * i, total - 1)];
+}
+template <int NA>
+__device__ __forceinline__ void head_st_f4(const f32x4 (&av)[NA], float* __restrict__ dst, int tid, int total) {
+#pragma unroll
+  for (int i = 0; i < NA; ++i)
+    if (tid + 256 * i < total) reinterpret_cast<f32x4*>(dst)[tid + 256 * i] = av[i];
+}
+template <int NS>
+__device__ __forceinline__ void head_ld_f1(float (&sv)[NS], const float* __restrict__ ap, const int (&goff)[NS]) {
+#pragma unroll
+  for (int i = 0; i < NS; ++i) sv[i] = ap[goff[i] < 0 ? 0 : goff[i]];
+}
+template <int NS>
+__device__ __forceinline__ void head_st_f1(const float (&sv)[NS], float* __restrict__ dst, const int (&goff)[NS],
+                                           const int (&loff)[NS]) {
+#pragma unroll
+  for (int i = 0; i < NS; ++i)
+    if (goff[i] >= 0) dst[loff[i]] = sv[i];
+}
+
+template <int W> struct HeadGeo;
+template <> struct HeadGeo<16> { static constexpr int PD = 3, PH = 6, PW = 18, RB = 4, CS = 336, CSK = 130; };
+template <> struct HeadGeo<8>  { static constexpr int PD = 3, PH = 10, PW = 10, RB = 8, CS = 304, CSK = 130; };
+template <> struct HeadGeo<4>  { static constexpr int PD = 6, PH = 6, PW = 6, RB = 4, CS = 240, CSK = 162; };
+// CS: channel stride of a slab in LDS = PD*PH*PW rounded up to 16 (mod 32): lanes (q, j) of a 32-lane group then hit 32
+// different banks; CSK: the same for the per-kd slab of the weight-gradient kernel where the lane's j is the channel
+// (stride 2 (mod 32): banks 2j + q).
+
+template <int W>
+__device__ __forceinline__ void head_block_origin(int b, int& d0, int& h0) {
+  if (W == 16) { d0 = b >> 2; h0 = (b & 3) * 4; }
+  else if (W == 8) { d0 = b; h0 = 0; }
+  else { d0 = 4 * b; h0 = 0; }
+}
+// position pb (0..63) of a block -> offset of its tap (0,0,0) corner inside the slab
+template <int W>
+__device__ __forceinline__ int head_block_off(int pb) {
+  typedef HeadGeo<W> G;
+  const int ww = pb % W, hh = (pb / W) % G::RB, dd = pb / (W * G::RB);
+  return (dd * G::PH + hh) * G::PW + ww;
+}
+
+// ---- forward.  grid (S/64, N, KSG); the block's channel range is walked in chunks of 8 channels (two MFMA k-groups).
+template <int W, int MT>
+__global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restrict__ a_pad, const float* __restrict__ Wf,
+                                                           const float* __restrict__ loc_b, const float* __restrict__ cl_b,
+                                                           float* __restrict__ locs, float* __restrict__ scores,
+                                                           float* __restrict__ slabs, int C, int D, int Ptot,
+                                                           int prior_off, int ncls, int co_total, int KSG) {
+  typedef HeadGeo<W> G;
+  constexpr int SLAB = G::PD * G::PH * G::PW, CH = 8;
+  constexpr int NS = (CH * SLAB + 255) / 256;          // slab floats per thread and chunk
+  constexpr int AF4 = 2 * 27 * MT * 64 / 4;            // weight fragments of a chunk, in float4
+  constexpr int NA = (AF4 + 255) / 256;
+  __shared__ __align__(16) float slab[CH * G::CS];
+  __shared__ __align__(16) float afr[AF4 * 4];
+  const int n = blockIdx.y, ksg = blockIdx.z, b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int S = D * W * W, Hp = W + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Hp;
+  int d0, h0;
+  head_block_origin<W>(b, d0, h0);
+  const int cpb = C / KSG, c_begin = ksg * cpb, nchunks = cpb / CH;
+  // chunk-invariant staging offsets of this thread
+  int goff[NS], loff[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int e = tid + 256 * i;
+    const int ch = e / SLAB, r = e % SLAB;
+    const int pd = r / (G::PH * G::PW), ph = (r / G::PW) % G::PH, pw = r % G::PW;
+    goff[i] = e < CH * SLAB ? (int)(ch * volp) + ((d0 + pd) * Hp + h0 + ph) * Hp + pw : -1;
+    loff[i] = ch * G::CS + r;
+  }
+  const float* abase = a_pad + ((size_t)n * C + c_begin) * volp;
+  const f32x4* wbase = reinterpret_cast<const f32x4*>(Wf + (size_t)(c_begin / 4) * 27 * MT * 64);
+  float sv[NS];
+  f32x4 av[NA];
+  const int ob = head_block_off<W>(wv * 16 + j);
+  f32x4 acc[MT];
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  head_ld_f1(sv, abase, goff);
+  head_ld_f4(av, wbase, tid, AF4);
+  for (int ck = 0; ck < nchunks; ++ck) {
+    __syncthreads();  // the previous chunk has been consumed
+    head_st_f1(sv, slab, goff, loff);
+    head_st_f4(av, afr, tid, AF4);
+    __syncthreads();
+    if (ck + 1 < nchunks) {  // in flight during this chunk's MFMAs
+      head_ld_f1(sv, abase + (size_t)(ck + 1) * CH * volp, goff);
+      head_ld_f4(av, wbase + (size_t)(ck + 1) * AF4, tid, AF4);
+    }
+#pragma unroll
+    for (int cgl = 0; cgl < 2; ++cgl) {
+      const float* sp = slab + (cgl * 4 + q) * G::CS + ob;
+      const float* fp = afr + (size_t)cgl * 27 * MT * 64 + lane;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = kd * 9 + kh * 3 + kw;
+            const float bq = sp[(kd * G::PH + kh) * G::PW + kw];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[(tap * MT + m) * 64], bq, acc[m], 0, 0, 0);
+          }
+    }
+  }
+  const int P = b * 64 + wv * 16 + j;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) {
+    if (KSG == 1) {
+      write_head_outputs(acc[m], m, q, n, P, S, loc_b, cl_b, locs, scores, Ptot, prior_off, ncls, co_total);
+    } else {  // slabs[ksg][n][P][16*MT], folded by head_fwd_finalize_kernel
+      float* dst = slabs + (((size_t)ksg * gridDim.y + n) * S + P) * (16 * MT) + m * 16 + 4 * q;
+      *reinterpret_cast<f32x4*>(dst) = acc[m];
+    }
+  }
+}
+
+// ---- bwd-data.  grid (S/64, ceil(C/16 / cts), N): the dO slab of the block is staged once, the weight fragments per
+// 16-channel tile.
+template <int W, int MT>
+__global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __restrict__ dO_pad,
+                                                                const float* __restrict__ Wb, float* __restrict__ g_a,
+                                                                int C, int D, int cts) {
+  typedef HeadGeo<W> G;
+  constexpr int SLAB = G::PD * G::PH * G::PW, CO = 16 * MT, COG = 4 * MT;
+  constexpr int NS = (CO * SLAB + 255) / 256;
+  constexpr int AF4 = COG * 27 * 64 / 4;
+  constexpr int NA = (AF4 + 255) / 256;
+  __shared__ __align__(16) float slab[CO * G::CS];
+  __shared__ __align__(16) float afr[AF4 * 4];
+  const int n = blockIdx.z, b = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int S = D * W * W, Hp = W + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Hp;
+  int d0, h0;
+  head_block_origin<W>(b, d0, h0);
+  const int ct_lo = blockIdx.y * cts, ct_hi = min(C / 16, ct_lo + cts);
+  {
+    const float* dp = dO_pad + (size_t)n * CO * volp;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      const int e = tid + 256 * i;
+      if (e < CO * SLAB) {
+        const int ch = e / SLAB, r = e % SLAB;
+        const int pd = r / (G::PH * G::PW), ph = (r / G::PW) % G::PH, pw = r % G::PW;
+        slab[ch * G::CS + r] = dp[(size_t)ch * volp + ((d0 + pd) * Hp + h0 + ph) * Hp + pw];
+      }
+    }
+  }
+  f32x4 av[NA];
+  const f32x4* wb4 = reinterpret_cast<const f32x4*>(Wb);
+  const int ob = head_block_off<W>(wv * 16 + j);
+  const int P = b * 64 + wv * 16 + j;
+  head_ld_f4(av, wb4 + (size_t)ct_lo * AF4, tid, AF4);
+  for (int ct = ct_lo; ct < ct_hi; ++ct) {
+    __syncthreads();  // the previous tile's fragments have been consumed (first pass: nothing)
+    head_st_f4(av, afr, tid, AF4);
+    __syncthreads();  // also publishes the dO slab on the first pass
+    if (ct + 1 < ct_hi) head_ld_f4(av, wb4 + (size_t)(ct + 1) * AF4, tid, AF4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int cog = 0; cog < COG; ++cog) {
+      const float* sp = slab + (cog * 4 + q) * G::CS + ob;
+      const float* fp = afr + (size_t)cog * 27 * 64 + lane;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tap = kd * 9 + kh * 3 + kw;
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[tap * 64], sp[((2 - kd) * G::PH + (2 - kh)) * G::PW + (2 - kw)], acc,
+                                                       0, 0, 0);
+          }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) g_a[((size_t)n * C + ct * 16 + 4 * q + r) * S + P] = acc[r];
+  }
+}
+
+// ---- bwd-weight.  grid (position splits, C/16, 3 tap planes): per 64-position block the 16-channel input slab of the
+// workgroup's kd plane and the dO values of the block are staged; a wave contracts its 16 positions (4 MFMA k-steps)
+// against the 9 taps of the plane.  Same slab / bias-slab layout as head_bwd_weight_kernel.
+template <int W, int MT>
+__global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restrict__ dO_pad, const float* __restrict__ a_pad,
+                                                           float* __restrict__ slabs, float* __restrict__ bias_slabs, int N,
+                                                           int C, int D, int blocks_per_wg) {
+  typedef HeadGeo<W> G;
+  constexpr int PDK = G::PD - 2, SLABK = PDK * G::PH * G::PW, CO = 16 * MT, DLD = 66;
+  constexpr int NS = (16 * SLABK + 255) / 256;
+  constexpr int ND = (CO * 64 + 255) / 256;
+  constexpr int STAGE = 16 * G::CSK + CO * DLD, REDN = 10 * MT * 256;
+  __shared__ __align__(16) float lds[STAGE > REDN ? STAGE : REDN];
+  float* fslab = lds;                 // [16 ci][CSK]
+  float* dtile = lds + 16 * G::CSK;   // [CO][DLD]: dO at the block's 64 positions
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int S = D * W * W, Hp = W + 2, bpi = S / 64;
+  const size_t volp = (size_t)(D + 2) * Hp * Hp;
+  const int ct = blockIdx.y, kd = blockIdx.z;
+  const bool do_bias = ct == 0 && kd == 0;
+  const int total = N * bpi;
+  const int blk_lo = blockIdx.x * blocks_per_wg, blk_hi = min(total, blk_lo + blocks_per_wg);
+  // block-invariant parts of the staging offsets
+  int gsp[NS], lsp[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int e = tid + 256 * i;
+    const int ch = e / SLABK, r = e % SLABK;
+    const int pd = r / (G::PH * G::PW), ph = (r / G::PW) % G::PH, pw = r % G::PW;
+    gsp[i] = e < 16 * SLABK ? (int)(ch * volp) + ((kd + pd) * Hp + ph) * Hp + pw : -1;
+    lsp[i] = ch * G::CSK + r;
+  }
+  int gdo[ND], ldo[ND];
+#pragma unroll
+  for (int i = 0; i < ND; ++i) {
+    const int e = tid + 256 * i;
+    const int co = e >> 6, pb = e & 63;
+    const int ww = pb % W, hh = (pb / W) % G::RB, dd = pb / (W * G::RB);
+    gdo[i] = e < CO * 64 ? (int)(co * volp) + ((dd + 1) * Hp + hh + 1) * Hp + ww + 1 : -1;
+    ldo[i] = co * DLD + pb;
+  }
+  float sv[NS], dv[ND];
+  auto block_org = [&](int blk, const float*& ap, const float*& dp) {
+    const int n = blk / bpi, b = blk - n * bpi;
+    int d0, h0;
+    head_block_origin<W>(b, d0, h0);
+    const int org = (d0 * Hp + h0) * Hp;
+    ap = a_pad + ((size_t)n * C + ct * 16) * volp + org;
+    dp = dO_pad + (size_t)n * CO * volp + org;
+  };
+  f32x4 acc[10 * MT];  // [0, 9*MT): taps (kh, kw) of plane kd; [9*MT, 10*MT): bias
+#pragma unroll
+  for (int i = 0; i < 10 * MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (blk_lo < blk_hi) {
+    const float *ap, *dp;
+    block_org(blk_lo, ap, dp);
+    head_ld_f1(sv, ap, gsp);
+    head_ld_f1(dv, dp, gdo);
+  }
+  for (int blk = blk_lo; blk < blk_hi; ++blk) {
+    __syncthreads();
+    head_st_f1(sv, fslab, gsp, lsp);
+    head_st_f1(dv, dtile, gdo, ldo);
+    __syncthreads();
+    if (blk + 1 < blk_hi) {
+      const float *ap, *dp;
+      block_org(blk + 1, ap, dp);
+      head_ld_f1(sv, ap, gsp);
+      head_ld_f1(dv, dp, gdo);
+    }
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int pb = wv * 16 + 4 * s + q;
+      const float* sp = fslab + j * G::CSK + head_block_off<W>(pb);
+      float a[MT];
+#pragma unroll
+      for (int m = 0; m < MT; ++m) a[m] = dtile[(m * 16 + j) * DLD + pb];
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float bq = sp[kh * G::PW + kw];
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[(kh * 3 + kw) * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bq, acc[(kh * 3 + kw) * MT + m], 0, 0, 0);
+        }
+      if (do_bias) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m)
+          acc[9 * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], 1.0f, acc[9 * MT + m], 0, 0, 0);
+      }
+    }
+  }
+  // fixed-order reduction over the 4 waves
+  float* red = lds;
+  __syncthreads();
+  for (int w2 = 3; w2 >= 1; --w2) {
+    if (wv == w2) {
+#pragma unroll
+      for (int i = 0; i < 10 * MT; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float* p = red + ((size_t)i * 4 + r) * 64 + lane;
+          if (w2 == 3) *p = acc[i][r];
+          else *p += acc[i][r];
+        }
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {
+    float* out = slabs + (((size_t)blockIdx.x * gridDim.y + ct) * 27 + kd * 9) * (MT * 256);
+#pragma unroll
+    for (int i = 0; i < 9 * MT; ++i)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        out[(size_t)i * 256 + (4 * q + r) * 16 + j] = acc[i][r] + red[((size_t)i * 4 + r) * 64 + lane];
+    if (do_bias && j == 0) {
+#pragma unroll
+      for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          bias_slabs[(size_t)blockIdx.x * 16 * MT + m * 16 + 4 * q + r] =
+              acc[9 * MT + m][r] + red[((size_t)(9 * MT + m) * 4 + r) * 64 + lane];
+    }
+  }
+}
+
+// the LDS-staged kernels take cubic W = H in {4, 8, 16} feature maps (W = 4: whole groups of 4 planes) and 16 output
+// channels (12 + 2*2: two classes)
+inline int head_lds_w(int C, int D, int H, int W, int MT = 1) {
+  static const int on = getenv("MSL_HEAD_LDS") ? atoi(getenv("MSL_HEAD_LDS")) : 1;
+  if (!on || MT != 1 || H != W || C % 16 != 0 || (D * H * W) % 64 != 0) return 0;
+  if (W == 16 || W == 8) return W;
+  if (W == 4 && D % 4 == 0) return 4;
+  return 0;
+}
+
 inline int head_mt(int ncls) { return (12 + 2 * ncls + 15) / 16; }
 
 inline int head_ksg(int N, int C, int S) {
@@ -386,19 +724,39 @@ inline int head_ksg(int N, int C, int S) {
 }
 
 struct HwPlan {
-  int steps, nblocks;
+  int lds_w;            // 0: register-fed kernel (steps / nblocks); else the LDS-staged kernel (bpw blocks per workgroup)
+  int steps, nblocks, bpw;
 };
-// Position blocks of the weight-gradient kernel: tiles = (C/16) x 3 tap planes; about 256 workgroups in total, at least 8
-// MFMA k-steps per wave.  Every position block costs one partial slab of the whole weight tensor.
-inline HwPlan head_bw_plan(int N, int C, int S) {
-  const int total_steps = msl::cdiv(N * S, 4);
-  const int tiles = (C / 16) * 3;
-  int want_blocks = std::max(1, 256 / tiles);  // blocks along the position axis
-  int steps = std::max(8, msl::cdiv(total_steps, want_blocks * 4));
+// Position splits of the weight-gradient kernels: tiles = (C/16) x 3 tap planes; about 256 workgroups in total.  Every
+// position split costs one partial slab of the whole weight tensor.
+inline HwPlan head_bw_plan(int N, int C, int D, int H, int W, int MT) {
+  const int S = D * H * W, tiles = (C / 16) * 3;
   HwPlan p;
-  p.steps = steps;
-  p.nblocks = msl::cdiv(total_steps, steps * 4);
+  p.lds_w = head_lds_w(C, D, H, W, MT);
+  const int want_blocks = std::max(1, 256 / tiles);
+  if (p.lds_w) {
+    const int total = N * (S / 64);
+    p.bpw = msl::cdiv(total, std::min(want_blocks, total));
+    p.nblocks = msl::cdiv(total, p.bpw);
+    p.steps = 0;
+    return p;
+  }
+  const int total_steps = msl::cdiv(N * S, 4);
+  p.steps = std::max(8, msl::cdiv(total_steps, want_blocks * 4));
+  p.nblocks = msl::cdiv(total_steps, p.steps * 4);
+  p.bpw = 0;
   return p;
+}
+// K split of the forward kernel over workgroups (partial slabs + head_fwd_finalize_kernel)
+inline int head_fwd_ksg(int N, int C, int D, int H, int W, int MT) {
+  const int S = D * H * W;
+  if (head_lds_w(C, D, H, W, MT)) {
+    const int blocks = N * (S / 64);
+    int ksg = 1;
+    while (blocks * ksg < 256 && C / (ksg * 2) >= 8 && (C / (ksg * 2)) % 8 == 0) ksg *= 2;
+    return ksg;
+  }
+  return head_ksg(N, C, S);
 }
 
 }  // namespace
@@ -419,7 +777,7 @@ int msl_head_pack_weights(const float* loc_w, const float* cl_w, float* Wf, floa
 }
 
 size_t msl_head_fwd_workspace_bytes(int N, int C, int D, int H, int W, int ncls) {
-  const int S = D * H * W, ksg = head_ksg(N, C, S);
+  const int S = D * H * W, ksg = head_fwd_ksg(N, C, D, H, W, head_mt(ncls));
   return ksg > 1 ? (size_t)ksg * N * S * 16 * head_mt(ncls) * sizeof(float) : 0;
 }
 
@@ -429,13 +787,23 @@ int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, c
                       int prior_off, int ncls, void* stream) {
   if (N <= 0 || C % 16 != 0 || D <= 0 || H <= 0 || W <= 0 || ncls < 1 || head_mt(ncls) > 2) return MSL_ERR_ARG;
   const int S = D * H * W, MT = head_mt(ncls), co_total = 12 + 2 * ncls;
-  const int ksg = head_ksg(N, C, S);
+  const int ksg = head_fwd_ksg(N, C, D, H, W, MT);
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(msl::cdiv(S, 32), N, ksg);
-  if (MT == 1)
-    hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
-  else
-    hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
+  const int lw = head_lds_w(C, D, H, W, MT);
+  if (lw) {
+    dim3 grid(S / 64, N, ksg);
+#define MSL_HF(W_, MT_)                                                                                              \
+  hipLaunchKernelGGL((head_fwd_lds_kernel<W_, MT_>), grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores,   \
+                     workspace, C, D, Ptot, prior_off, ncls, co_total, ksg)
+    if (lw == 16) MSL_HF(16, 1); else if (lw == 8) MSL_HF(8, 1); else MSL_HF(4, 1);
+#undef MSL_HF
+  } else {
+    dim3 grid(msl::cdiv(S, 32), N, ksg);
+    if (MT == 1)
+      hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
+    else
+      hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
+  }
   MSL_LAUNCH_CHECK();
   if (ksg > 1) {
     const int total = N * S * 4 * MT;
@@ -462,23 +830,37 @@ int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int
                            int ncls, void* stream) {
   if (C % 16 != 0) return MSL_ERR_ARG;
   const int S = D * H * W, MT = head_mt(ncls);
+  hipStream_t st = (hipStream_t)stream;
+  const int lw = head_lds_w(C, D, H, W, MT);
+  if (lw) {
+    const int blocks = N * (S / 64), ctiles = C / 16;
+    const int gy = std::max(1, std::min(ctiles, 256 / blocks));
+    const int cts = msl::cdiv(ctiles, gy);
+    dim3 grid(S / 64, msl::cdiv(ctiles, cts), N);
+#define MSL_HB(W_, MT_) \
+  hipLaunchKernelGGL((head_bwd_data_lds_kernel<W_, MT_>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, cts)
+    if (lw == 16) MSL_HB(16, 1); else if (lw == 8) MSL_HB(8, 1); else MSL_HB(4, 1);
+#undef MSL_HB
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
   dim3 grid(msl::cdiv(S, 32), msl::cdiv(C, 64), N);
-  if (MT == 1) hipLaunchKernelGGL(head_bwd_data_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, dO_pad, Wb, g_a, C, D, H, W);
-  else hipLaunchKernelGGL(head_bwd_data_kernel<2>, grid, dim3(256), 0, (hipStream_t)stream, dO_pad, Wb, g_a, C, D, H, W);
+  if (MT == 1) hipLaunchKernelGGL(head_bwd_data_kernel<1>, grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+  else hipLaunchKernelGGL(head_bwd_data_kernel<2>, grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
 
 // workspace = [nblocks][C/16][27*MT][16][16] weight slabs followed by [nblocks][16*MT] bias slabs
 size_t msl_head_bwd_weight_workspace_bytes(int N, int C, int D, int H, int W, int ncls) {
-  HwPlan p = head_bw_plan(N, C, D * H * W);
+  HwPlan p = head_bw_plan(N, C, D, H, W, head_mt(ncls));
   return ((size_t)p.nblocks * (C / 16) * 27 * head_mt(ncls) * 256 + (size_t)p.nblocks * 16 * head_mt(ncls)) * sizeof(float);
 }
 
 // number of slabs msl_head_conv_bwd_weight leaves in its workspace
-int msl_head_conv_bwd_weight_nslabs(int N, int C, int D, int H, int W) {
-  if (N <= 0 || C % 16 != 0 || D <= 0 || H <= 0 || W <= 0) return MSL_ERR_ARG;
-  return head_bw_plan(N, C, D * H * W).nblocks;
+int msl_head_conv_bwd_weight_nslabs(int N, int C, int D, int H, int W, int ncls) {
+  if (N <= 0 || C % 16 != 0 || D <= 0 || H <= 0 || W <= 0 || ncls < 1) return MSL_ERR_ARG;
+  return head_bw_plan(N, C, D, H, W, head_mt(ncls)).nblocks;
 }
 
 // dloc_w == NULL (then dcl_w / dloc_b / dcl_b are ignored): leave the partial slabs in `workspace` (deferred reduction:
@@ -488,16 +870,24 @@ int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dlo
                              float* dloc_b, float* dcl_b, float* workspace, int N, int C, int D, int H, int W,
                              int ncls, void* stream) {
   if (C % 16 != 0) return MSL_ERR_ARG;
-  const int S = D * H * W, MT = head_mt(ncls), co_total = 12 + 2 * ncls;
-  HwPlan p = head_bw_plan(N, C, S);
+  const int MT = head_mt(ncls), co_total = 12 + 2 * ncls;
+  HwPlan p = head_bw_plan(N, C, D, H, W, MT);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(p.nblocks, C / 16, 3);
-  const size_t lds = (size_t)10 * MT * 256 * sizeof(float);
   float* bias_slabs = workspace + (size_t)p.nblocks * (C / 16) * 27 * MT * 256;
-  if (MT == 1) {
-    hipLaunchKernelGGL(head_bwd_weight_kernel<1>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
+  if (p.lds_w) {
+#define MSL_HW(W_, MT_)                                                                                               \
+  hipLaunchKernelGGL((head_bww_lds_kernel<W_, MT_>), grid, dim3(256), 0, st, dO_pad, a_pad, workspace, bias_slabs, N, \
+                     C, D, p.bpw)
+    if (p.lds_w == 16) MSL_HW(16, 1); else if (p.lds_w == 8) MSL_HW(8, 1); else MSL_HW(4, 1);
+#undef MSL_HW
   } else {
-    hipLaunchKernelGGL(head_bwd_weight_kernel<2>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
+    const size_t lds = (size_t)10 * MT * 256 * sizeof(float);
+    if (MT == 1) {
+      hipLaunchKernelGGL(head_bwd_weight_kernel<1>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
+    } else {
+      hipLaunchKernelGGL(head_bwd_weight_kernel<2>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
+    }
   }
   MSL_LAUNCH_CHECK();
   if (!dloc_w) return MSL_OK;

@@ -153,29 +153,39 @@ __global__ __launch_bounds__(256) void match_prior_best_kernel(const float* __re
   obj[(size_t)n * P + p] = bi;
 }
 
-// best prior per object: first maximum over priors (ssd3d.py:812).  One workgroup per object.
-__global__ __launch_bounds__(256) void match_object_best_kernel(const float* __restrict__ gt_boxes,
-                                                                const float* __restrict__ priors_c,
-                                                                int* __restrict__ prior_for_obj, int P) {
-  __shared__ float sv[256];
-  __shared__ int si[256];
+// best prior per object: first maximum over priors (ssd3d.py:812).  One workgroup (1024 threads) per object; a thread
+// visits priors tid, tid + 1024, ... four at a time with their 24 loads in flight together (the serial form spent 36
+// dependent memory round trips per thread: 15 us for a dozen objects).
+constexpr int MOB_T = 1024;
+__global__ __launch_bounds__(MOB_T) void match_object_best_kernel(const float* __restrict__ gt_boxes,
+                                                                  const float* __restrict__ priors_c,
+                                                                  int* __restrict__ prior_for_obj, int P) {
+  __shared__ float sv[MOB_T];
+  __shared__ int si[MOB_T];
   const int o = blockIdx.x;
   const Box g = load_box(gt_boxes + (size_t)o * 6);
   const float gv = box_vol(g);
   float best = 0.f;
   int bi = -1;
-  for (int p = threadIdx.x; p < P; p += 256) {
-    const Box pb = c_to_xyz(load_box(priors_c + (size_t)p * 6));
-    const float v = box_iou(g, gv, pb, box_vol(pb));
-    if (bi < 0 || v > best) {  // ascending p within a thread: strict > keeps the first
-      best = v;
-      bi = p;
+  for (int p0 = threadIdx.x; p0 < P; p0 += 4 * MOB_T) {
+    Box c[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) c[u] = load_box(priors_c + (size_t)min(p0 + u * MOB_T, P - 1) * 6);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int p = p0 + u * MOB_T;
+      const Box pb = c_to_xyz(c[u]);
+      const float v = box_iou(g, gv, pb, box_vol(pb));
+      if (p < P && (bi < 0 || v > best)) {  // ascending p within a thread: strict > keeps the first
+        best = v;
+        bi = p;
+      }
     }
   }
   sv[threadIdx.x] = best;
   si[threadIdx.x] = bi;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = MOB_T / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) {
       const float v2 = sv[threadIdx.x + s];
       const int i2 = si[threadIdx.x + s];
@@ -657,7 +667,7 @@ int msl_multibox_match(const float* gt_boxes, const long long* gt_labels, const 
   if (total_objects > 0) {
     hipLaunchKernelGGL(match_prior_best_kernel, gp, dim3(256), 0, st, gt_boxes, obj_off, priors_c, overlap, obj, P);
     MSL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_object_best_kernel, dim3(total_objects), dim3(256), 0, st, gt_boxes, priors_c,
+    hipLaunchKernelGGL(match_object_best_kernel, dim3(total_objects), dim3(MOB_T), 0, st, gt_boxes, priors_c,
                        prior_for_obj, P);
     MSL_LAUNCH_CHECK();
     hipLaunchKernelGGL(match_force_kernel, dim3(N), dim3(256), 0, st, obj_off, prior_for_obj, overlap, obj, P);

@@ -479,6 +479,156 @@ __global__ __launch_bounds__(NWK == 1 ? 256 : NWK * 64) void pw_wave_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Column-strip variant for the big layers (blocks 1-3: K <= 128, >= 128 strips).  A workgroup owns COLS consecutive
+// positions of one image and ALL M output rows: the activated input strip [K][COLS] is read from HBM exactly once
+// (coalesced 16-byte loads, affine + ReLU applied on the way into LDS), the weight rows of a wave stay in registers, and
+// each of the 4 waves finishes its own 32-row x (32*TPW)-column part - one barrier in the whole kernel, no cross-wave
+// reduction, statistics straight from the accumulators.  The wave-autonomous form above re-reads the input strip once
+// per 32-row tile (M/32 times through L2) and needs K/64 waves to meet in LDS for every tile.
+template <int K, int COLS, int MT, bool AFFINE, bool STATS, bool TRANS_W>
+__global__ __launch_bounds__(256) void pw_strip_kernel(const float* __restrict__ X, const float* __restrict__ in_scale,
+                                                       const float* __restrict__ in_shift, const float* __restrict__ Wt,
+                                                       float* __restrict__ Y, double* __restrict__ partials, int S,
+                                                       msl::BnFold fold) {
+  constexpr int M = 32 * MT, CT = COLS / 32, TPW = MT * CT / 4, KH = K / 2;
+  static_assert(TPW >= 1 && (TPW <= CT) && CT % TPW == 0, "a wave owns TPW column tiles of one row tile");
+  constexpr int LPT = K * COLS / 4 / 256;  // float4 loads per thread for the strip
+  constexpr int C4 = COLS / 4;             // float4 per strip row
+  __shared__ __align__(16) float Xs[K * COLS];
+  __shared__ float f_sc[AFFINE ? K : 1], f_sh[AFFINE ? K : 1];
+  __shared__ float rs[(STATS && TPW != CT) ? 4 * 32 * 2 : 1];
+  const int n = blockIdx.y, s0 = blockIdx.x * COLS;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, h = lane >> 5, c = lane & 31;
+  const int t0 = wv * TPW, mt = t0 / CT, ct0 = t0 % CT;
+  const int m0 = mt * 32;
+  const float* Xn = X + (size_t)n * K * S + s0;
+  // the strip: thread -> rows r0 + i * (256 / C4), one float4 each
+  typedef float f32x4v __attribute__((ext_vector_type(4)));
+  f32x4v xv[LPT];
+  const int r0 = tid / C4, c4 = (tid % C4) * 4;
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) xv[i] = *reinterpret_cast<const f32x4v*>(Xn + (size_t)(r0 + i * (256 / C4)) * S + c4);
+  // this wave's weight rows: lane (h, c) holds W[m0 + c][h*KH + kk]
+  float wr[KH];
+  if (!TRANS_W) {
+    const f32x4v* wp = reinterpret_cast<const f32x4v*>(Wt + (size_t)(m0 + c) * K + h * KH);
+#pragma unroll
+    for (int j = 0; j < KH / 4; ++j) {
+      const f32x4v t = wp[j];
+      wr[4 * j] = t.x; wr[4 * j + 1] = t.y; wr[4 * j + 2] = t.z; wr[4 * j + 3] = t.w;
+    }
+  } else {
+    const float* wp = Wt + (size_t)(h * KH) * M + m0 + c;
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) wr[kk] = wp[(size_t)kk * M];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (AFFINE) {
+    if (fold.partials) {
+      msl::bn_fold_block(fold, 0, K, f_sc, f_sh);  // ends with a barrier
+    } else {
+      if (tid < K) {
+        f_sc[tid] = in_scale[tid];
+        f_sh[tid] = in_shift[tid];
+      }
+      __syncthreads();
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < LPT; ++i) {
+    const int r = r0 + i * (256 / C4);
+    f32x4v v = xv[i];
+    if (AFFINE) {
+      const float sc = f_sc[r], sh = f_sh[r];
+      v.x = msl::act(v.x, sc, sh); v.y = msl::act(v.y, sc, sh); v.z = msl::act(v.z, sc, sh); v.w = msl::act(v.w, sc, sh);
+    }
+    *reinterpret_cast<f32x4v*>(&Xs[r * COLS + c4]) = v;
+  }
+  __syncthreads();
+  f32x16 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) acc[t] = (f32x16){0};
+  const float* xb = Xs + (size_t)(h * KH) * COLS + ct0 * 32 + c;
+#pragma unroll
+  for (int kk = 0; kk < KH; ++kk)
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[kk], xb[kk * COLS + t * 32], acc[t], 0, 0, 0);
+  // D[row][col]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  float* Yn = Y + (size_t)n * M * S + s0 + ct0 * 32 + c;
+  const int NP = gridDim.y * gridDim.x, p = n * gridDim.x + blockIdx.x;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * h;
+    float v = 0.f, v2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      const float a = acc[t][r];
+      Yn[(size_t)row * S + t * 32] = a;
+      v += a;
+      v2 = fmaf(a, a, v2);
+    }
+    if (STATS) {
+      const float sm = msl::half32_sum(v), q = msl::half32_sum(v2);
+      if (TPW == CT) {  // the wave covers the whole strip of its rows
+        if (c == msl::HALF32_SUM_LANE && partials) {
+          partials[(size_t)row * NP + p] = (double)sm;
+          partials[((size_t)M + row) * NP + p] = (double)q;
+        }
+      } else if (c == msl::HALF32_SUM_LANE) {  // CT / TPW waves share a row tile: their row sums meet in LDS below
+        rs[(wv * 32 + row - m0) * 2] = sm;
+        rs[(wv * 32 + row - m0) * 2 + 1] = q;
+      }
+    }
+  }
+  if (STATS && TPW != CT) {
+    constexpr int PW = CT / TPW;  // consecutive waves share a row tile
+    __syncthreads();
+    if (tid < M && partials) {
+      const int w0 = (tid / 32) * PW, rl = tid % 32;
+      double sm = 0.0, q = 0.0;
+#pragma unroll
+      for (int u = 0; u < PW; ++u) {
+        sm += (double)rs[((w0 + u) * 32 + rl) * 2];
+        q += (double)rs[((w0 + u) * 32 + rl) * 2 + 1];
+      }
+      partials[(size_t)tid * NP + p] = sm;
+      partials[((size_t)M + tid) * NP + p] = q;
+    }
+  }
+}
+
+// which (K, M, S) take the column-strip kernel, and with which strip width (0: none): the forward and bwd-data GEMMs of
+// blocks 1-3 (K = input channels of the GEMM, M = output rows)
+static inline int strip_cols(int N, int K, int M, int S) {
+  static const int on = getenv("MSL_PW_STRIP") ? atoi(getenv("MSL_PW_STRIP")) : 1;
+  if (!on) return 0;
+  int cols = 0;
+  if (K == 32 && M == 64) cols = 256;
+  else if (K == 64 && M == 32) cols = 128;
+  else if ((K == 64 && M == 128) || (K == 128 && (M == 128 || M == 64))) cols = 64;
+  // (32-column strips - two workgroups per CU - measured equal or slower: 8.2 -> 9.4 us and 11.1 -> 12.4 us on blocks 2 / 3)
+  if (!cols || S % cols != 0 || (long long)N * (S / cols) < 128) return 0;
+  return cols;
+}
+
+template <bool AFFINE, bool STATS, bool TRANS_W>
+static int launch_strip(const float* X, const float* in_scale, const float* in_shift, const float* Wt, float* Y,
+                        double* partials, int N, int M, int K, int S, int cols, const msl::BnFold& fold, hipStream_t st) {
+  dim3 grid(S / cols, N);
+#define MSL_ST(K_, C_, MT_) \
+  hipLaunchKernelGGL((pw_strip_kernel<K_, C_, MT_, AFFINE, STATS, TRANS_W>), grid, dim3(256), 0, st, X, in_scale, in_shift, Wt, Y, partials, S, fold)
+  if (K == 32 && M == 64) MSL_ST(32, 256, 2);
+  else if (K == 64 && M == 32) MSL_ST(64, 128, 1);
+  else if (K == 64 && M == 128) MSL_ST(64, 64, 4);
+  else if (K == 128 && M == 128) MSL_ST(128, 64, 4);
+  else if (K == 128 && M == 64) MSL_ST(128, 64, 2);
+  else return MSL_ERR_UNSUPPORTED;
+#undef MSL_ST
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
 // column tiles per wave of the unsplit form (K <= 64): two when that still leaves >= 2 waves per SIMD - the weight rows, the
 // input affine and the statistics reduction are then paid once per 64 columns
 static inline int wave_nt(int N, int K, int M, int S) {
@@ -820,6 +970,7 @@ static inline bool use_ksplit(int K, int M, int S, int N) {
 }
 
 int msl_pwconv_fwd_num_partials(int N, int Cin, int Cout, int S) {
+  if (const int cols = strip_cols(N, Cin, Cout, S)) return N * (S / cols);
   if (wave_form(Cin, Cout)) return N * msl::cdiv(S, Cin <= 64 ? 128 * wave_nt(N, Cin, Cout, S) : 32);
   return N * msl::cdiv(S, use_ksplit(Cin, Cout, S, N) ? KS_BN : BN);
 }
@@ -832,6 +983,14 @@ static int pwconv_fwd_impl(const float* z, const float* in_scale, const float* i
   if (N <= 0 || S <= 0 || Cin % BK != 0 || Cout % 4 != 0) return MSL_ERR_ARG;
   if ((in_scale || fold.partials) && Cin > FOLD_MAXK) return MSL_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (const int cols = strip_cols(N, Cin, Cout, S)) {
+    if (in_scale || fold.partials) {
+      if (partials) return launch_strip<true, true, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, cols, fold, st);
+      return launch_strip<true, false, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, cols, fold, st);
+    }
+    if (partials) return launch_strip<false, true, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, cols, fold, st);
+    return launch_strip<false, false, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, cols, fold, st);
+  }
   if (wave_form(Cin, Cout)) {
     if (in_scale || fold.partials) {
       if (partials) return launch_wave<true, true, false>(z, in_scale, in_shift, w, y, partials, N, Cout, Cin, S, fold, st);
@@ -896,6 +1055,9 @@ int msl_pwconv_fwd_fold(const float* z, const double* in_partials, int in_np, do
 int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int Cin, int Cout, int S,
                         void* stream) {
   if (N <= 0 || S <= 0 || Cout % BK != 0 || Cin % 4 != 0) return MSL_ERR_ARG;
+  if (const int cols = strip_cols(N, Cout, Cin, S))
+    return launch_strip<false, false, true>(dy, nullptr, nullptr, w, g_in, nullptr, N, Cin, Cout, S, cols, pw_nofold,
+                                            (hipStream_t)stream);
   if (wave_form(Cout, Cin))
     return launch_wave<false, false, true>(dy, nullptr, nullptr, w, g_in, nullptr, N, Cin, Cout, S, pw_nofold,
                                            (hipStream_t)stream);

@@ -196,7 +196,7 @@ class Plan:
                 npd = L.msl_dwconv_bwd_weight_num_partials(N, specs[i]["cin"], pd, ph, pw, specs[i]["stride"][0])
                 self.dw_np.append(npd)
                 self.dw_part.append(torch.empty(specs[i]["cin"] * 27 * npd, dtype=torch.float64, device=device))
-            self.head_nslabs = {f: L.msl_head_conv_bwd_weight_nslabs(N, specs[f]["cout"], *self.dims[f]) for f in self.feat_ids}
+            self.head_nslabs = {f: L.msl_head_conv_bwd_weight_nslabs(N, specs[f]["cout"], *self.dims[f], ncls) for f in self.feat_ids}
             self.stem_nslabs = L.msl_stem_conv_bwd_weight_nslabs(N, *self.in_dims, *specs[0]["stride"])
             self.grad_tables = {}
             # fused stem backward (block 1 is a stride-2 depthwise layer fed by a 32-channel stem that is not a head
@@ -283,6 +283,8 @@ class Engine:
         key = (device.type, device.index)
         if key not in self.side:
             pr = int(os.environ.get("MSL_SIDE_STREAM_PRIORITY", "0"))
+            # (restricting the side streams to a CU subset with hipExtStreamCreateWithCUMask was measured 8-9 % slower for
+            # every mask - half, quarter, three quarters of the chip - so they are ordinary streams)
             self.side[key] = (torch.cuda.Stream(device=device, priority=pr), torch.cuda.Stream(device=device, priority=pr))
         return self.side[key]
 

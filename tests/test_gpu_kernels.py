@@ -299,7 +299,9 @@ def _fused_stem_case(cin, dims):
                                           # S % 32 == 0: the wave-autonomous weight-gradient kernel (whole range in one
                                           # workgroup / split over slabs / odd chunk counts per wave / 32-row tiles)
                                           (4, 512, 512, 64), (4, 256, 512, 64), (2, 128, 256, 512), (3, 64, 128, 4096),
-                                          (2, 32, 64, 32768), (1, 32, 96, 96), (1, 64, 32, 32), (3, 96, 160, 1120)])
+                                          (2, 32, 64, 32768), (1, 32, 96, 96), (1, 64, 32, 32), (3, 96, 160, 1120),
+                                          # the column-strip kernels of blocks 1-3 (forward and bwd-data)
+                                          (2, 128, 128, 4096), (4, 64, 128, 4096), (1, 32, 64, 65536)])
 def test_pw_fwd_bwd(N, Cin, Cout, S):
     L = _lib.load()
     z = rnd(N, Cin, S, seed=10)
@@ -465,7 +467,13 @@ def test_bn_forward_backward():
 
 # ------------------------------------------------------------------------------------------------- heads
 @pytest.mark.parametrize("N,C,dims,ncls", [(2, 128, (8, 8, 8), 2), (2, 32, (3, 5, 6), 2), (1, 256, (4, 4, 4), 2),
-                                           (2, 64, (2, 2, 2), 2), (1, 32, (4, 4, 4), 3)])
+                                           (2, 64, (2, 2, 2), 2), (1, 32, (4, 4, 4), 3),
+                                           # the LDS-staged kernels: W = H in {16, 8, 4}, with and without a channel
+                                           # split of the forward pass, several tiles per workgroup in bwd-data, odd
+                                           # block counts per workgroup in the weight gradient, D != W
+                                           (2, 128, (16, 16, 16), 2), (4, 256, (8, 8, 8), 2), (4, 512, (4, 4, 4), 2),
+                                           (1, 16, (16, 16, 16), 2), (3, 48, (8, 8, 8), 2), (1, 32, (8, 4, 4), 2),
+                                           (5, 16, (12, 8, 8), 2), (1, 32, (16, 16, 16), 3)])
 def test_heads_fwd_bwd(N, C, dims, ncls):
     L = _lib.load()
     a = torch.relu(rnd(N, C, *dims, seed=30)).requires_grad_(True)

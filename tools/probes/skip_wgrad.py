@@ -1,7 +1,9 @@
-"""Timing experiment (WRONG RESULTS, probe only): how much wall time do the off-chain weight gradients cost?
+"""Timing experiments (WRONG RESULTS where noted, probe only): what do the side streams cost / buy?
 
-The product engine has no switch for this; the probe subclasses the launch helper and drops every launch whose tag
-names a weight gradient.  Usage (GPU box): python tools/probes/skip_wgrad.py
+  full step (three streams) | everything on one stream | weight gradients skipped (wrong results)
+
+The product engine has no switch for skipping work; the probe wraps the launch helper and drops every launch whose tag names
+a weight gradient.  Usage (GPU box): python tools/probes/skip_wgrad.py
 """
 import os
 import sys
@@ -16,10 +18,10 @@ from mslesions3d_amd.ssd3d import LSSD3D, MultiBoxLoss  # noqa: E402
 from mslesions3d_amd.synth import make_batch_on_device  # noqa: E402
 from mslesions3d_amd.trainer import FusedTrainer  # noqa: E402
 
-SKIP = ("pw_bww", "dw_bww", "head_bww")
+SKIP = ("pw_bww", "dw_bww", "head_bww", "grad_reduce")
 
 
-def run(skip):
+def run(skip=False, multi_stream=True):
     orig = eng_mod.Engine._k
 
     def _k(self, tag, name, *args):
@@ -32,20 +34,23 @@ def run(skip):
         dev = torch.device("cuda", 0)
         torch.manual_seed(0)
         model = LSSD3D(n_classes=2, input_channels=1, input_size=(128,) * 3, threshold=[0.1, 0.2], lr=1e-3).to(dev).train()
+        model._engine.multi_stream = multi_stream
         tr = FusedTrainer(model)
         x, b, l = make_batch_on_device(4, (128,) * 3, dev, 1, seed=1)
         packed = (x,) + MultiBoxLoss.pack_targets(b, l, dev)
         for _ in range(10):
-            tr.step_packed(*packed, sync=False)
+            tr.step_packed(*packed, sync=False, resident=True)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(100):
-            tr.step_packed(*packed, sync=False)
+        for _ in range(200):
+            tr.step_packed(*packed, sync=False, resident=True)
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / 100 * 1e3
+        return (time.perf_counter() - t0) / 200 * 1e3
     finally:
         eng_mod.Engine._k = orig
 
 
 if __name__ == "__main__":
-    print(f"full step {run(False):.3f} ms; weight gradients skipped (wrong results) {run(True):.3f} ms")
+    print(f"full step {run():.3f} ms; one stream {run(multi_stream=False):.3f} ms; "
+          f"weight gradients skipped (wrong results) {run(skip=True):.3f} ms; "
+          f"one stream, weight gradients skipped {run(skip=True, multi_stream=False):.3f} ms")
