@@ -154,6 +154,9 @@ int msl_pwconv_bwd_weight_slabs(const float* dy, const float* z, const float* in
 size_t msl_head_packed_weight_elems(int C, int ncls);
 int msl_head_pack_weights(const float* loc_w, const float* cl_w, float* Wf, float* Wb, int C, int ncls,
                           void* stream);
+/* the same for all (<= 4) scales of the model in one launch; the five arrays have n entries and live on the host */
+int msl_head_pack_weights_batch(const float* const* loc_w, const float* const* cl_w, float* const* Wf, float* const* Wb,
+                                const int* C, int n, int ncls, void* stream);
 size_t msl_head_fwd_workspace_bytes(int N, int C, int D, int H, int W, int ncls);
 int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, const float* cl_b, float* locs,
                       float* scores, float* workspace, int N, int C, int D, int H, int W, int Ptot, int prior_off,

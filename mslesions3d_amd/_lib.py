@@ -65,6 +65,7 @@ _SIGNATURES = {
     "msl_grad_reduce_batch": (_I, [_P, _I, _I, _P]),
     "msl_head_packed_weight_elems": (_Z, [_I, _I]),
     "msl_head_pack_weights": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "msl_head_pack_weights_batch": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
     "msl_head_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "msl_head_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_head_grad_pack": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

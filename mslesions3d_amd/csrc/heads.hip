@@ -54,6 +54,47 @@ __global__ void head_pack_weights_kernel(const float* __restrict__ loc_w, const 
   }
 }
 
+// all scales of the model in one launch (blockIdx.y = scale): the packed copies are refreshed once per step
+struct HeadPackBatch {
+  const float* loc_w[4];
+  const float* cl_w[4];
+  float* Wf[4];
+  float* Wb[4];
+  int C[4];
+};
+__global__ void head_pack_weights_batch_kernel(HeadPackBatch b, int co_total, int MT) {
+  const int k = blockIdx.y;
+  const float *loc_w = b.loc_w[k], *cl_w = b.cl_w[k];
+  float *Wf = b.Wf[k], *Wb = b.Wb[k];
+  const int C = b.C[k];
+  const int total = C / 4 * 27 * MT * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63;
+    {
+      int r = i >> 6;
+      const int mt = r % MT;
+      r /= MT;
+      const int tap = r % 27, cg = r / 27;
+      const int co = mt * 16 + (lane & 15), ci = 4 * cg + (lane >> 4);
+      float v = 0.f;
+      if (co < 12) v = loc_w[((size_t)co * C + ci) * 27 + tap];
+      else if (co < co_total) v = cl_w[((size_t)(co - 12) * C + ci) * 27 + tap];
+      Wf[i] = v;
+    }
+    {
+      int r = i >> 6;
+      const int tap = r % 27;
+      r /= 27;
+      const int cog = r % (4 * MT), ct = r / (4 * MT);
+      const int co = 4 * cog + (lane >> 4), ci = 16 * ct + (lane & 15);
+      float v = 0.f;
+      if (co < 12) v = loc_w[((size_t)co * C + ci) * 27 + tap];
+      else if (co < co_total) v = cl_w[((size_t)(co - 12) * C + ci) * 27 + tap];
+      Wb[i] = v;
+    }
+  }
+}
+
 __device__ __forceinline__ void write_head_outputs(const f32x4 v, int mt, int q, int n, int P, int S,
                                                    const float* loc_b, const float* cl_b, float* locs,
                                                    float* scores, int Ptot, int prior_off, int ncls,
@@ -432,7 +473,10 @@ __device__ __forceinline__ int head_block_off(int pb) {
   return (dd * G::PH + hh) * G::PW + ww;
 }
 
-// ---- forward.  grid (S/64, N, KSG); the block's channel range is walked in chunks of 8 channels (two MFMA k-groups).
+// ---- forward.  grid (S/64, N, KSG); the block's channel range is walked in chunks of HEAD_FWD_CH channels.  The next
+// chunk's loads are issued one chunk ahead: a chunk must hold about as much MFMA time (27 per k-group of 4 channels,
+// 32 cycles each) as an L2 round trip takes under load (~1.5 us), or every chunk waits for its loads - 16 channels.
+constexpr int HEAD_FWD_CH = 16;
 template <int W, int MT>
 __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restrict__ a_pad, const float* __restrict__ Wf,
                                                            const float* __restrict__ loc_b, const float* __restrict__ cl_b,
@@ -440,9 +484,9 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
                                                            float* __restrict__ slabs, int C, int D, int Ptot,
                                                            int prior_off, int ncls, int co_total, int KSG) {
   typedef HeadGeo<W> G;
-  constexpr int SLAB = G::PD * G::PH * G::PW, CH = 8;
+  constexpr int SLAB = G::PD * G::PH * G::PW, CH = HEAD_FWD_CH, NCG = CH / 4;
   constexpr int NS = (CH * SLAB + 255) / 256;          // slab floats per thread and chunk
-  constexpr int AF4 = 2 * 27 * MT * 64 / 4;            // weight fragments of a chunk, in float4
+  constexpr int AF4 = NCG * 27 * MT * 64 / 4;          // weight fragments of a chunk, in float4
   constexpr int NA = (AF4 + 255) / 256;
   __shared__ __align__(16) float slab[CH * G::CS];
   __shared__ __align__(16) float afr[AF4 * 4];
@@ -468,9 +512,11 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
   float sv[NS];
   f32x4 av[NA];
   const int ob = head_block_off<W>(wv * 16 + j);
-  f32x4 acc[MT];
+  // two accumulator chains per output tile (even / odd taps): a 16x16x4 fp32 MFMA issues every 32 cycles but a dependent
+  // one only every 40, and a wave has one tile
+  f32x4 acc[MT], acc2[MT];
 #pragma unroll
-  for (int m = 0; m < MT; ++m) acc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < MT; ++m) acc[m] = acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   head_ld_f1(sv, abase, goff);
   head_ld_f4(av, wbase, tid, AF4);
@@ -484,7 +530,7 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
       head_ld_f4(av, wbase + (size_t)(ck + 1) * AF4, tid, AF4);
     }
 #pragma unroll
-    for (int cgl = 0; cgl < 2; ++cgl) {
+    for (int cgl = 0; cgl < NCG; ++cgl) {
       const float* sp = slab + (cgl * 4 + q) * G::CS + ob;
       const float* fp = afr + (size_t)cgl * 27 * MT * 64 + lane;
 #pragma unroll
@@ -496,11 +542,15 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
             const int tap = kd * 9 + kh * 3 + kw;
             const float bq = sp[(kd * G::PH + kh) * G::PW + kw];
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[(tap * MT + m) * 64], bq, acc[m], 0, 0, 0);
+            for (int m = 0; m < MT; ++m) {
+              if (tap & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[(tap * MT + m) * 64], bq, acc2[m], 0, 0, 0);
+              else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[(tap * MT + m) * 64], bq, acc[m], 0, 0, 0);
+            }
           }
     }
   }
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] += acc2[m];
   const int P = b * 64 + wv * 16 + j;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
@@ -555,7 +605,7 @@ __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __r
     head_st_f4(av, afr, tid, AF4);
     __syncthreads();  // also publishes the dO slab on the first pass
     if (ct + 1 < ct_hi) head_ld_f4(av, wb4 + (size_t)(ct + 1) * AF4, tid, AF4);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains: see head_fwd_lds_kernel
 #pragma unroll 1
     for (int cog = 0; cog < COG; ++cog) {
       const float* sp = slab + (cog * 4 + q) * G::CS + ob;
@@ -567,10 +617,12 @@ __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __r
 #pragma unroll
           for (int kw = 0; kw < 3; ++kw) {
             const int tap = kd * 9 + kh * 3 + kw;
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[tap * 64], sp[((2 - kd) * G::PH + (2 - kh)) * G::PW + (2 - kw)], acc,
-                                                       0, 0, 0);
+            const float bq = sp[((2 - kd) * G::PH + (2 - kh)) * G::PW + (2 - kw)];
+            if (tap & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[tap * 64], bq, acc2, 0, 0, 0);
+            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[tap * 64], bq, acc, 0, 0, 0);
           }
     }
+    acc += acc2;
 #pragma unroll
     for (int r = 0; r < 4; ++r) g_a[((size_t)n * C + ct * 16 + 4 * q + r) * S + P] = acc[r];
   }
@@ -578,19 +630,21 @@ __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __r
 
 // ---- bwd-weight.  grid (position splits, C/16, 3 tap planes): per 64-position block the 16-channel input slab of the
 // workgroup's kd plane and the dO values of the block are staged; a wave contracts its 16 positions (4 MFMA k-steps)
-// against the 9 taps of the plane.  Same slab / bias-slab layout as head_bwd_weight_kernel.
+// against the 9 taps of the plane.  HEAD_BWW_SB blocks form one stage (36 MFMAs per wave and block are 0.5 us, an L2
+// round trip under load ~1.5 us: with one block per stage every stage waited for its loads).  Same slab / bias-slab
+// layout as head_bwd_weight_kernel.
+constexpr int HEAD_BWW_SB = 4;
 template <int W, int MT>
 __global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restrict__ dO_pad, const float* __restrict__ a_pad,
                                                            float* __restrict__ slabs, float* __restrict__ bias_slabs, int N,
                                                            int C, int D, int blocks_per_wg) {
   typedef HeadGeo<W> G;
-  constexpr int PDK = G::PD - 2, SLABK = PDK * G::PH * G::PW, CO = 16 * MT, DLD = 66;
+  constexpr int PDK = G::PD - 2, SLABK = PDK * G::PH * G::PW, CO = 16 * MT, DLD = 66, SB = HEAD_BWW_SB;
   constexpr int NS = (16 * SLABK + 255) / 256;
   constexpr int ND = (CO * 64 + 255) / 256;
-  constexpr int STAGE = 16 * G::CSK + CO * DLD, REDN = 10 * MT * 256;
+  constexpr int FSZ = 16 * G::CSK, DSZ = CO * DLD;
+  constexpr int STAGE = SB * (FSZ + DSZ), REDN = 10 * MT * 256;
   __shared__ __align__(16) float lds[STAGE > REDN ? STAGE : REDN];
-  float* fslab = lds;                 // [16 ci][CSK]
-  float* dtile = lds + 16 * G::CSK;   // [CO][DLD]: dO at the block's 64 positions
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
   const int S = D * W * W, Hp = W + 2, bpi = S / 64;
   const size_t volp = (size_t)(D + 2) * Hp * Hp;
@@ -617,56 +671,60 @@ __global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restri
     gdo[i] = e < CO * 64 ? (int)(co * volp) + ((dd + 1) * Hp + hh + 1) * Hp + ww + 1 : -1;
     ldo[i] = co * DLD + pb;
   }
-  float sv[NS], dv[ND];
-  auto block_org = [&](int blk, const float*& ap, const float*& dp) {
-    const int n = blk / bpi, b = blk - n * bpi;
-    int d0, h0;
-    head_block_origin<W>(b, d0, h0);
-    const int org = (d0 * Hp + h0) * Hp;
-    ap = a_pad + ((size_t)n * C + ct * 16) * volp + org;
-    dp = dO_pad + (size_t)n * CO * volp + org;
+  float sv[SB][NS], dv[SB][ND];
+  // loads of the stage that starts at block b0 (blocks past the range are clamped: their products are skipped)
+  auto load_stage = [&](int b0) {
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      const int blk = min(b0 + u, blk_hi - 1);
+      const int n = blk / bpi, b = blk - n * bpi;
+      int d0, h0;
+      head_block_origin<W>(b, d0, h0);
+      const int org = (d0 * Hp + h0) * Hp;
+      head_ld_f1(sv[u], a_pad + ((size_t)n * C + ct * 16) * volp + org, gsp);
+      head_ld_f1(dv[u], dO_pad + (size_t)n * CO * volp + org, gdo);
+    }
   };
   f32x4 acc[10 * MT];  // [0, 9*MT): taps (kh, kw) of plane kd; [9*MT, 10*MT): bias
 #pragma unroll
   for (int i = 0; i < 10 * MT; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  if (blk_lo < blk_hi) {
-    const float *ap, *dp;
-    block_org(blk_lo, ap, dp);
-    head_ld_f1(sv, ap, gsp);
-    head_ld_f1(dv, dp, gdo);
-  }
-  for (int blk = blk_lo; blk < blk_hi; ++blk) {
+  if (blk_lo < blk_hi) load_stage(blk_lo);
+  for (int b0 = blk_lo; b0 < blk_hi; b0 += SB) {
     __syncthreads();
-    head_st_f1(sv, fslab, gsp, lsp);
-    head_st_f1(dv, dtile, gdo, ldo);
-    __syncthreads();
-    if (blk + 1 < blk_hi) {
-      const float *ap, *dp;
-      block_org(blk + 1, ap, dp);
-      head_ld_f1(sv, ap, gsp);
-      head_ld_f1(dv, dp, gdo);
+#pragma unroll
+    for (int u = 0; u < SB; ++u) {
+      head_st_f1(sv[u], lds + u * (FSZ + DSZ), gsp, lsp);
+      head_st_f1(dv[u], lds + u * (FSZ + DSZ) + FSZ, gdo, ldo);
     }
+    __syncthreads();
+    if (b0 + SB < blk_hi) load_stage(b0 + SB);
+#pragma unroll 1
+    for (int u = 0; u < SB; ++u) {
+      if (b0 + u >= blk_hi) break;  // uniform
+      const float* fslab = lds + u * (FSZ + DSZ);
+      const float* dtile = fslab + FSZ;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const int pb = wv * 16 + 4 * s + q;
-      const float* sp = fslab + j * G::CSK + head_block_off<W>(pb);
-      float a[MT];
+      for (int s = 0; s < 4; ++s) {
+        const int pb = wv * 16 + 4 * s + q;
+        const float* sp = fslab + j * G::CSK + head_block_off<W>(pb);
+        float a[MT];
 #pragma unroll
-      for (int m = 0; m < MT; ++m) a[m] = dtile[(m * 16 + j) * DLD + pb];
+        for (int m = 0; m < MT; ++m) a[m] = dtile[(m * 16 + j) * DLD + pb];
 #pragma unroll
-      for (int kh = 0; kh < 3; ++kh)
+        for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) {
-          const float bq = sp[kh * G::PW + kw];
+          for (int kw = 0; kw < 3; ++kw) {
+            const float bq = sp[kh * G::PW + kw];
+#pragma unroll
+            for (int m = 0; m < MT; ++m)
+              acc[(kh * 3 + kw) * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bq, acc[(kh * 3 + kw) * MT + m], 0, 0, 0);
+          }
+        if (do_bias) {
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[(kh * 3 + kw) * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bq, acc[(kh * 3 + kw) * MT + m], 0, 0, 0);
+            acc[9 * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], 1.0f, acc[9 * MT + m], 0, 0, 0);
         }
-      if (do_bias) {
-#pragma unroll
-        for (int m = 0; m < MT; ++m)
-          acc[9 * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], 1.0f, acc[9 * MT + m], 0, 0, 0);
       }
     }
   }
@@ -753,7 +811,7 @@ inline int head_fwd_ksg(int N, int C, int D, int H, int W, int MT) {
   if (head_lds_w(C, D, H, W, MT)) {
     const int blocks = N * (S / 64);
     int ksg = 1;
-    while (blocks * ksg < 256 && C / (ksg * 2) >= 8 && (C / (ksg * 2)) % 8 == 0) ksg *= 2;
+    while (blocks * ksg < 256 && C / (ksg * 2) >= HEAD_FWD_CH && (C / (ksg * 2)) % HEAD_FWD_CH == 0) ksg *= 2;
     return ksg;
   }
   return head_ksg(N, C, S);
@@ -772,6 +830,25 @@ int msl_head_pack_weights(const float* loc_w, const float* cl_w, float* Wf, floa
   const int total = C / 4 * 27 * MT * 64;
   hipLaunchKernelGGL(head_pack_weights_kernel, dim3(std::min(msl::cdiv(total, 256), 1024)), dim3(256), 0,
                      (hipStream_t)stream, loc_w, cl_w, Wf, Wb, C, 12 + 2 * ncls, MT);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// the same for up to 4 scales in ONE launch; the arrays (n entries each) live on the HOST
+int msl_head_pack_weights_batch(const float* const* loc_w, const float* const* cl_w, float* const* Wf, float* const* Wb,
+                                const int* C, int n, int ncls, void* stream) {
+  if (n < 1 || n > 4 || ncls < 1 || head_mt(ncls) > 2) return MSL_ERR_ARG;
+  HeadPackBatch b;
+  int cmax = 0;
+  for (int k = 0; k < n; ++k) {
+    if (C[k] % 16 != 0) return MSL_ERR_ARG;
+    b.loc_w[k] = loc_w[k]; b.cl_w[k] = cl_w[k]; b.Wf[k] = Wf[k]; b.Wb[k] = Wb[k]; b.C[k] = C[k];
+    cmax = std::max(cmax, C[k]);
+  }
+  const int MT = head_mt(ncls);
+  const int total = cmax / 4 * 27 * MT * 64;
+  hipLaunchKernelGGL(head_pack_weights_batch_kernel, dim3(std::min(msl::cdiv(total, 256), 512), n), dim3(256), 0,
+                     (hipStream_t)stream, b, 12 + 2 * ncls, MT);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -383,6 +383,7 @@ class Engine:
         feats = m.base.features
         specs = self.layer_specs
         _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
+        self._pack_head_weights(pl, st)  # MFMA-fragment copies of the head weights, all scales, once per pass
 
         fold_max = (1 << 30) if self.fold_bn else self.fold_np_max
         folds = lambda NP: training and NP <= fold_max  # is the BatchNorm with NP partials folded into its consumers?
@@ -523,6 +524,21 @@ class Engine:
             return
         _lib.call("msl_bn_finalize_batch", ptr(pl.bn_table), pl.bn_table_n, pl.bn_table_channels, st, tag="bn_finalize_all")
 
+    def _pack_head_weights(self, pl, st):
+        import ctypes
+        m = self.model
+        key = tuple(ptr(c.weight) for c in m.pred_convs.loc_convs) + tuple(ptr(c.weight) for c in m.pred_convs.cl_convs)
+        if getattr(pl, "pack_key", None) != key:
+            n = len(pl.feat_ids)
+            P = ctypes.c_void_p * n
+            pl.pack_args = (P(*[ptr(c.weight) for c in m.pred_convs.loc_convs]), P(*[ptr(c.weight) for c in m.pred_convs.cl_convs]),
+                            P(*[ptr(pl.Wf[f]) for f in pl.feat_ids]), P(*[ptr(pl.Wb[f]) for f in pl.feat_ids]),
+                            (ctypes.c_int * n)(*[self.layer_specs[f]["cout"] for f in pl.feat_ids]))
+            pl.pack_key = key
+        a = pl.pack_args  # host arrays: kept alive by the plan (a recorded launch program points at them)
+        self._k("head_pack", "msl_head_pack_weights_batch", ctypes.addressof(a[0]), ctypes.addressof(a[1]), ctypes.addressof(a[2]),
+                ctypes.addressof(a[3]), ctypes.addressof(a[4]), len(pl.feat_ids), m.n_classes, st)
+
     def _head_forward(self, pl, f, st):
         m = self.model
         ncls = m.n_classes
@@ -530,7 +546,6 @@ class Engine:
         lc, cc = m.pred_convs.loc_convs[k], m.pred_convs.cl_convs[k]
         C = self.layer_specs[f]["cout"]
         D, H, W = pl.dims[f]
-        self._k(f"head_pack{f}", "msl_head_pack_weights", ptr(lc.weight), ptr(cc.weight), ptr(pl.Wf[f]), ptr(pl.Wb[f]), C, ncls, st)
         self._k(f"head_fwd{f}", "msl_head_conv_fwd", ptr(pl.fpad[f]), ptr(pl.Wf[f]), ptr(lc.bias), ptr(cc.bias), ptr(pl.locs),
                 ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
 

@@ -361,7 +361,7 @@ def test_training_loop_with_fresh_batches_replays_one_program():
         if s >= 30:  # every target-capacity bucket has been seen by now
             mem.append(torch.cuda.memory_allocated())
     assert len(tr._programs) <= 3, len(tr._programs)     # one per target-capacity bucket (8 / 16 / 32 rows)
-    assert max(mem) - min(mem) <= 1 << 20, (min(mem), max(mem))
+    assert mem[-1] - min(mem) <= 1 << 20, (min(mem), mem[-1])  # no growth (the collector may FREE the eager model's plan on the way)
     # resident=True keeps the round-1 behaviour (programs keyed on the caller's tensors), LRU-bounded
     tr.max_programs = 4
     from mslesions3d_amd.ssd3d import MultiBoxLoss
