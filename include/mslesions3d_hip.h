@@ -172,6 +172,28 @@ int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dlo
                              float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls,
                              void* stream);
 
+/* ---- bf16 activation path (BASELINE configs[2]/[3]; the reference is fp32: a build-side extension) ------
+ * Activations are bf16 in HBM (raw conv outputs, NCDHW; `void*` = bf16 storage); weights, BatchNorm vectors and statistics
+ * and all accumulators stay fp32.  The forward kernels of the backbone + heads (mobilenet.py:26-49, ssd3d.py:113-169): */
+int msl_stem_conv_fwd_bf16(const float* x, const float* w, void* y_bf16, double* partials, int N, int Cin, int D,
+                           int H, int W, int sd, int sh, int sw, void* stream);
+int msl_dwconv_fwd_bf16_num_partials(int N, int C, int D, int H, int W, int stride);
+int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
+                        double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
+int msl_pwconv_fwd_bf16_num_partials(int N, int S);
+/* pointwise GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) */
+int msl_pwconv_fwd_bf16(const void* z, const float* in_scale, const float* in_shift, const float* w, void* y,
+                        double* partials, int N, int Cin, int Cout, int S, void* stream);
+/* relu(bn(y)) of a head feature map -> bf16 CHANNELS-LAST zero-haloed copy (N,D+2,H+2,W+2,C), halo zeroed by the caller */
+int msl_bn_relu_materialize_bf16(const void* y, const float* scale, const float* shift, float* plain, void* pad_cl, int N,
+                                 int C, int D, int H, int W, void* stream);
+size_t msl_head_packed_weight_bf16_elems(int C);
+int msl_head_pack_weights_bf16(const float* loc_w, const float* cl_w, void* Wp, int C, int ncls, void* stream);
+/* both head convolutions of a scale on v_mfma_f32_16x16x32_bf16, fp32 rows out */
+int msl_head_conv_fwd_bf16(const void* a_cl, const void* Wp, const float* loc_b, const float* cl_b, float* locs,
+                           float* scores, int N, int C, int D, int H, int W, int Ptot, int prior_off, int ncls,
+                           void* stream);
+
 /* ---- priors, box math, matching, MultiBox loss : ssd3d.py:286-342, utils.py:42-149, ssd3d.py:741-941 ------- */
 int msl_make_priors(float* out, int row_off, int D0, int D1, int D2, double scale, int boxes_per_location,
                     void* stream);

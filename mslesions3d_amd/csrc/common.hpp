@@ -137,6 +137,11 @@ __device__ __forceinline__ float act(float x, float s, float t) {
 
 __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) / b; }
 
+// ---- bf16 storage (bf16 activation path) ------------------------------------------------------------------------
+// Round-to-nearest-even through the compiler's __bf16 (v_cvt_pk_bf16_f32 on gfx950: NaN stays NaN); widening is exact.
+__device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+
 // ---- BatchNorm fold -------------------------------------------------------------------------------------------
 // Turning the fp64 (sum, sumsq) partials of a producer into its per-channel affine is cheap, but as a kernel of its
 // own it sits on the forward dependency chain (15 launches of ~6 us).  So the CONSUMER kernels fold the partials of

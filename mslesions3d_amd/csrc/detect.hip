@@ -205,25 +205,44 @@ __global__ __launch_bounds__(256) void detect_mask_kernel(const float* __restric
   }
 }
 
-// one wave per (n, class).  keep word w lives in lane w.
-__global__ __launch_bounds__(64) void detect_scan_kernel(const unsigned long long* __restrict__ mask,
-                                                         const int* __restrict__ ncand, int cap, int Wn,
-                                                         unsigned long long* __restrict__ keep_bits,
-                                                         int* __restrict__ nkept) {
-  const int nc = blockIdx.x, lane = threadIdx.x;
+// one workgroup per (n, class); the serial walk is done by wave 0 (keep word w lives in lane w).  The mask rows do not
+// depend on the scan state: when they fit (M * Wn words <= SCAN_LDS) all 256 threads first copy them into LDS, so that
+// the walk reads LDS (64 groups of 8 rows: ~150 cycles each) instead of waiting for a global round trip per group of 8
+// rows (1.5-2 us each: 112 us at 500 candidates).
+constexpr int SCAN_LDS = 6144;  // 64-bit words (48 KB)
+__global__ __launch_bounds__(256) void detect_scan_kernel(const unsigned long long* __restrict__ mask,
+                                                          const int* __restrict__ ncand, int cap, int Wn,
+                                                          unsigned long long* __restrict__ keep_bits,
+                                                          int* __restrict__ nkept) {
+  __shared__ unsigned long long lm[SCAN_LDS];
+  const int nc = blockIdx.x, lane = threadIdx.x & 63;
   const int M = min(ncand[nc], cap);
   const unsigned long long* mk = mask + (size_t)nc * cap * Wn;
+  const bool staged = (size_t)M * Wn <= SCAN_LDS;
+  if (staged) {
+    for (int e = threadIdx.x; e < M * Wn; e += 256) lm[e] = mk[e];
+    __syncthreads();
+  }
+  if (threadIdx.x >= 64) return;
   unsigned long long supp = 0ull;
   for (int i0 = 0; i0 < M; i0 += 8) {
-    // the mask rows do not depend on the scan state: 8 of them are fetched before the serial walk over them
+    // 8 rows are fetched before the serial walk over them
     unsigned long long rows[8];
+    if (staged) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) rows[u] = (lane < Wn && i0 + u < M) ? mk[(size_t)(i0 + u) * Wn + lane] : 0ull;
+      for (int u = 0; u < 8; ++u) rows[u] = (lane < Wn && i0 + u < M) ? lm[(i0 + u) * Wn + lane] : 0ull;
+    } else {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) rows[u] = (lane < Wn && i0 + u < M) ? mk[(size_t)(i0 + u) * Wn + lane] : 0ull;
+    }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + u;
       if (i < M) {  // wave-uniform
-        const unsigned long long wi = __shfl(supp, i >> 6, 64);
+        // word i >> 6 of the suppression mask lives in that lane: a scalar lane read (v_readlane)
+        const int wl = __builtin_amdgcn_readfirstlane(i >> 6);
+        const unsigned long long wi = ((unsigned long long)(unsigned)__builtin_amdgcn_readlane((int)(supp >> 32), wl) << 32) |
+                                      (unsigned)__builtin_amdgcn_readlane((int)(supp & 0xffffffffull), wl);
         if (!((wi >> (i & 63)) & 1ull)) {                           // wave-uniform
           supp |= rows[u];                                          // ssd3d.py:422
           if (lane == (i >> 6)) supp &= ~(1ull << (i & 63));       // ssd3d.py:426
@@ -310,15 +329,31 @@ __global__ __launch_bounds__(256) void detect_finalize_kernel(const float* __res
     for (int i = threadIdx.x; i < total; i += 256) lts[i] = ts[i];
     __syncthreads();
   }
-  const float* rs = in_lds ? lts : ts;
   for (int i = threadIdx.x; i < total; i += 256) {
     int pos = i;
     if (resort) {
-      const float si = rs[i];
+      // rank = number of candidates that sort in front (stable, descending).  Two explicit loops: a pointer chosen at
+      // run time between LDS and global memory is a generic pointer, and 2 x 500 flat loads per thread made this kernel
+      // 150 us; the LDS form reads a broadcast word per step.
       pos = 0;
-      for (int j = 0; j < total; ++j) {
-        const float sj = rs[j];
-        pos += (sj > si) || (sj == si && j < i);
+      if (in_lds) {
+        const float si = lts[i];
+        int j = 0;
+        for (; j + 4 <= total; j += 4) {
+          const float s0 = lts[j], s1 = lts[j + 1], s2 = lts[j + 2], s3 = lts[j + 3];
+          pos += ((s0 > si) || (s0 == si && j < i)) + ((s1 > si) || (s1 == si && j + 1 < i)) +
+                 ((s2 > si) || (s2 == si && j + 2 < i)) + ((s3 > si) || (s3 == si && j + 3 < i));
+        }
+        for (; j < total; ++j) {
+          const float sj = lts[j];
+          pos += (sj > si) || (sj == si && j < i);
+        }
+      } else {
+        const float si = ts[i];
+        for (int j = 0; j < total; ++j) {
+          const float sj = ts[j];
+          pos += (sj > si) || (sj == si && j < i);
+        }
       }
     }
     if (pos < top_k) {
@@ -369,7 +404,7 @@ int msl_detect_objects(const float* locs, const float* scores, const float* prio
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(detect_mask_kernel, dim3(msl::cdiv(cap, 4), N * ncls1), dim3(256), 0, st, boxes, sorted_idx, ncand, max_overlap, P, cap, Wn, ncls1, mask);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(detect_scan_kernel, dim3(N * ncls1), dim3(64), 0, st, mask, ncand, cap, Wn, keep_bits, nkept);
+  hipLaunchKernelGGL(detect_scan_kernel, dim3(N * ncls1), dim3(256), 0, st, mask, ncand, cap, Wn, keep_bits, nkept);
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(detect_finalize_kernel, dim3(N), dim3(256), 0, st, probs, boxes, sorted_idx, keep_bits, nkept, P, cap, Wn, ncls1, top_k, out_boxes, out_scores, out_labels, out_prior, out_count, tmp_scores, tmp_ref);
   MSL_LAUNCH_CHECK();

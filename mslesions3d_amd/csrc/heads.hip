@@ -772,6 +772,89 @@ inline int head_lds_w(int C, int D, int H, int W, int MT = 1) {
   return 0;
 }
 
+// =====================================================================================================================
+// bf16 activation path (csrc/bf16.hip): the head convolutions on v_mfma_f32_16x16x32_bf16.  The feature map is the bf16
+// CHANNELS-LAST zero-haloed copy (N, D+2, H+2, W+2, C) written by msl_bn_relu_materialize_bf16, so the B operand of a
+// k-step - 8 consecutive channels of one voxel per lane - is ONE 16-byte load; k-step = (tap, 32-channel group).  The
+// weights are packed per step as [tap][C/32][lane][8] bf16 (co = lane & 15, ci = 32*cg + 8*(lane >> 4) + j; rows >= 12 +
+// 2*ncls are zero).  Outputs are the same fp32 (N, P, 6) / (N, P, ncls) rows as the fp32 kernels write.
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short hu16;
+typedef hu16 hu16x8 __attribute__((ext_vector_type(8)));
+
+__global__ void head_pack_weights_bf16_kernel(const float* __restrict__ loc_w, const float* __restrict__ cl_w,
+                                              hu16* __restrict__ Wp, int C, int co_total) {
+  const int total = 27 * (C / 32) * 64;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int lane = i & 63;
+    const int cg = (i >> 6) % (C / 32), tap = (i >> 6) / (C / 32);
+    const int co = lane & 15;
+    hu16x8 o;
+#pragma unroll
+    for (int jj = 0; jj < 8; ++jj) {
+      const int ci = cg * 32 + 8 * (lane >> 4) + jj;
+      float v = 0.f;
+      if (co < 12) v = loc_w[((size_t)co * C + ci) * 27 + tap];
+      else if (co < co_total) v = cl_w[((size_t)(co - 12) * C + ci) * 27 + tap];
+      o[jj] = msl::f2bf(v);
+    }
+    *reinterpret_cast<hu16x8*>(Wp + (size_t)i * 8) = o;
+  }
+}
+
+// grid (ceil(S / 64), N); a wave owns one 16-position tile and walks the 27 * C/32 k-steps four at a time: the 8
+// operand loads of a group (16 bytes per lane each) leave together, so a wave has ~8 KB in flight instead of one
+// dependent round trip per MFMA (the first version: 90 us per scale, latency-bound).
+__global__ __launch_bounds__(256) void head_fwd_bf16_kernel(const hu16* __restrict__ a_cl, const hu16* __restrict__ Wp,
+                                                            const float* __restrict__ loc_b, const float* __restrict__ cl_b,
+                                                            float* __restrict__ locs, float* __restrict__ scores, int C,
+                                                            int D, int H, int W, int Ptot, int prior_off, int ncls,
+                                                            int co_total) {
+  const int n = blockIdx.y;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+  const int S = D * H * W, Hp = H + 2, Wp2 = W + 2, CG = C / 32;
+  const int p0 = (blockIdx.x * 4 + wv) * 16;
+  int P = p0 + j;
+  if (P >= S) P = S - 1;
+  const int w = P % W, h = (P / W) % H, d = P / (W * H);
+  const hu16* ab = a_cl + ((((size_t)n * (D + 2) + d) * Hp + h) * Wp2 + w) * C + 8 * g;  // tap (0,0,0), this lane's channels
+  const hu16* wp = Wp + (size_t)lane * 8;
+  f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};  // two chains (even / odd k-steps)
+  const int nsteps = 27 * CG;  // CG is a multiple of 4 for C in {128, 256, 512}; other C: the tail loop
+  int step = 0;
+  int tap = 0, cg = 0;
+  size_t toff = 0;
+  auto advance = [&]() {  // (tap, cg) -> next k-step; toff = element offset of the tap
+    if (++cg == CG) {
+      cg = 0;
+      ++tap;
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      toff = (((size_t)kd * Hp + kh) * Wp2 + kw) * C;
+    }
+  };
+  for (; step + 4 <= nsteps; step += 4) {
+    hbf16x8 a[4], b[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      a[u] = *reinterpret_cast<const hbf16x8*>(wp + ((size_t)tap * CG + cg) * 512);
+      b[u] = *reinterpret_cast<const hbf16x8*>(ab + toff + cg * 32);
+      advance();
+    }
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[0], b[0], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[1], b[1], acc1, 0, 0, 0);
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[2], b[2], acc0, 0, 0, 0);
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[3], b[3], acc1, 0, 0, 0);
+  }
+  for (; step < nsteps; ++step) {
+    const hbf16x8 a = *reinterpret_cast<const hbf16x8*>(wp + ((size_t)tap * CG + cg) * 512);
+    const hbf16x8 b = *reinterpret_cast<const hbf16x8*>(ab + toff + cg * 32);
+    advance();
+    acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc0, 0, 0, 0);
+  }
+  acc0 += acc1;
+  write_head_outputs(acc0, 0, g, n, p0 + j, S, loc_b, cl_b, locs, scores, Ptot, prior_off, ncls, co_total);
+}
+
 inline int head_mt(int ncls) { return (12 + 2 * ncls + 15) / 16; }
 
 inline int head_ksg(int N, int C, int S) {
@@ -849,6 +932,31 @@ int msl_head_pack_weights_batch(const float* const* loc_w, const float* const* c
   const int total = cmax / 4 * 27 * MT * 64;
   hipLaunchKernelGGL(head_pack_weights_batch_kernel, dim3(std::min(msl::cdiv(total, 256), 512), n), dim3(256), 0,
                      (hipStream_t)stream, b, 12 + 2 * ncls, MT);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// ---- bf16 activation path -------------------------------------------------------------------------------------------
+size_t msl_head_packed_weight_bf16_elems(int C) { return (size_t)27 * (C / 32) * 64 * 8; }
+
+int msl_head_pack_weights_bf16(const float* loc_w, const float* cl_w, void* Wp, int C, int ncls, void* stream) {
+  if (C % 32 != 0 || ncls < 1 || 12 + 2 * ncls > 16) return MSL_ERR_UNSUPPORTED;
+  const int total = 27 * (C / 32) * 64;
+  hipLaunchKernelGGL(head_pack_weights_bf16_kernel, dim3(std::min(msl::cdiv(total, 256), 512)), dim3(256), 0,
+                     (hipStream_t)stream, loc_w, cl_w, (hu16*)Wp, C, 12 + 2 * ncls);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// a_cl (N,D+2,H+2,W+2,C) bf16 channels-last -> rows [prior_off, prior_off + 2*D*H*W) of locs / scores (fp32)
+int msl_head_conv_fwd_bf16(const void* a_cl, const void* Wp, const float* loc_b, const float* cl_b, float* locs,
+                           float* scores, int N, int C, int D, int H, int W, int Ptot, int prior_off, int ncls,
+                           void* stream) {
+  if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || ncls < 1) return MSL_ERR_ARG;
+  if (C % 32 != 0 || 12 + 2 * ncls > 16) return MSL_ERR_UNSUPPORTED;
+  const int S = D * H * W;
+  hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(msl::cdiv(S, 64), N), dim3(256), 0, (hipStream_t)stream, (const hu16*)a_cl,
+                     (const hu16*)Wp, loc_b, cl_b, locs, scores, C, D, H, W, Ptot, prior_off, ncls, 12 + 2 * ncls);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

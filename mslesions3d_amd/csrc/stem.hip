@@ -110,9 +110,10 @@ __global__ __launch_bounds__(256) void stem_fwd_kernel(const float* __restrict__
 //   B operand  lane (h, c): x at tap k = 2kk + h of output column c     - one global load per kk, straight to registers
 // (interior tiles take a mask-free path; volume borders a clamped-and-masked one).  Per-channel (sum, sumsq) are
 // carried per lane across the wave's chunks and reduced once at the end (DPP), fp64 partials [2][32][NP].
-template <int CIN>
+// BF16OUT: y is bf16 (round to nearest even at the store; the statistics are taken from the fp32 accumulators).
+template <int CIN, bool BF16OUT = false>
 __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            float* __restrict__ y, double* __restrict__ partials,
+                                                            void* __restrict__ y, double* __restrict__ partials,
                                                             int D, int H, int W, int OD, int OH, int OW, int sd, int sh,
                                                             int sw, int chunks_per_row, int chunks_per_n, int iters) {
   constexpr int K = CIN * 27, KS = (K + 1) / 2;
@@ -122,7 +123,8 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   const int n = blockIdx.y;
   const int OS = OD * OH * OW;
   const float* xn = x + (size_t)n * CIN * D * H * W;
-  float* yn = y + (size_t)n * STEM_COUT * OS;
+  constexpr int EB = BF16OUT ? 2 : 4;  // bytes per output element
+  char* yn = (char*)y + (size_t)n * STEM_COUT * OS * EB;
 
   float wa[KS];
   int tapoff[KS];  // element offset of the lane's tap kk inside the image
@@ -142,7 +144,11 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
       (void*)msl::uniform_base(xn), 0, (int)((unsigned)CIN * D * H * W * 4u), 0x00020000);
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-      (void*)msl::uniform_base(yn), 0, (int)((unsigned)STEM_COUT * OS * 4u), 0x00020000);
+      (void*)msl::uniform_base(yn), 0, (int)((unsigned)STEM_COUT * OS * (unsigned)EB), 0x00020000);
+  auto store_out = [&](float v, int voff, int soff) {
+    if (BF16OUT) __builtin_amdgcn_raw_buffer_store_b16((short)msl::f2bf(v), ry, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, soff, 0);
+  };
   int lanetap4[KS];  // byte offset of (tap kk, column c) relative to the tile's first tap
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) lanetap4[kk] = (c * sw + tapoff[kk]) * 4;
@@ -212,23 +218,22 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
       }
     }
   };
-  const int loff4 = (4 * h * OS + c) * 4;  // per lane, bytes: rows 4h.., column c
+  const int loff4 = (4 * h * OS + c) * EB;  // per lane, bytes: rows 4h.., column c
   auto finish_tile = [&](const Tile& t, const float (&b)[KS]) {
     f32x16 acc = {0};
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kk], b[kk], acc, 0, 0, 0);
     // D[row][col]: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
     const int owt = t.seg * 64 + t.half * 32;
-    const int yoff = __builtin_amdgcn_readfirstlane(((t.od * OH + t.oh) * OW + owt) * 4);  // scalar
+    const int yoff = __builtin_amdgcn_readfirstlane(((t.od * OH + t.oh) * OW + owt) * EB);  // scalar
     if (t.live && owt + 32 <= OW) {  // wave-uniform: whole tile inside
 #pragma unroll
-      for (int r = 0; r < 16; ++r)
-        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), ry, loff4, yoff + ((r & 3) + 8 * (r >> 2)) * OS * 4, 0);
+      for (int r = 0; r < 16; ++r) store_out(acc[r], loff4, yoff + ((r & 3) + 8 * (r >> 2)) * OS * EB);
     } else {
       const bool pv = t.live && owt + c < OW;
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        if (pv) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[r]), ry, loff4, yoff + ((r & 3) + 8 * (r >> 2)) * OS * 4, 0);
+        if (pv) store_out(acc[r], loff4, yoff + ((r & 3) + 8 * (r >> 2)) * OS * EB);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -672,9 +677,9 @@ static inline int stem_fwd_blocks(int OD, int OH, int OW) {
 
 int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW) { return N * stem_fwd_blocks(OD, OH, OW); }
 
-// x (N,Cin,D,H,W) -> y (N,32,OD,OH,OW) raw conv output + fp64 stat partials [2][32][NP].
-int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D,
-                      int H, int W, int sd, int sh, int sw, void* stream) {
+// x (N,Cin,D,H,W) -> y (N,32,OD,OH,OW) raw conv output (fp32, or bf16 when `bf16_out`) + fp64 stat partials [2][32][NP].
+static int stem_fwd_impl(const float* x, const float* w, void* y, double* partials, int N, int Cin, int D, int H, int W,
+                         int sd, int sh, int sw, bool bf16_out, void* stream) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || sd < 1 || sd > 2 || sh < 1 || sh > 2 || sw < 1 || sw > 2)
     return MSL_ERR_ARG;
   if ((long long)Cin * D * H * W >= (1ll << 30)) return MSL_ERR_UNSUPPORTED;  // in-image byte offsets are 32-bit
@@ -684,9 +689,15 @@ int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials
   const int iters = msl::cdiv(chunks_per_n, nb * 4);
   dim3 grid(nb, N);
   hipStream_t st = (hipStream_t)stream;
-#define MSL_STEM_FW(CI)                                                                                              \
-  hipLaunchKernelGGL(stem_fwd_mfma_kernel<CI>, grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, sh, \
-                     sw, chunks_per_row, chunks_per_n, iters)
+#define MSL_STEM_FW(CI)                                                                                                 \
+  do {                                                                                                                  \
+    if (bf16_out)                                                                                                       \
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<CI, true>), grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, \
+                         sd, sh, sw, chunks_per_row, chunks_per_n, iters);                                              \
+    else                                                                                                                \
+      hipLaunchKernelGGL((stem_fwd_mfma_kernel<CI, false>), grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, \
+                         OW, sd, sh, sw, chunks_per_row, chunks_per_n, iters);                                          \
+  } while (0)
   switch (Cin) {
     case 1: MSL_STEM_FW(1); break;
     case 2: MSL_STEM_FW(2); break;
@@ -697,6 +708,17 @@ int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials
 #undef MSL_STEM_FW
   MSL_LAUNCH_CHECK();
   return MSL_OK;
+}
+
+int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D,
+                      int H, int W, int sd, int sh, int sw, void* stream) {
+  return stem_fwd_impl(x, w, y, partials, N, Cin, D, H, W, sd, sh, sw, false, stream);
+}
+
+// the same with a bf16 output tensor (bf16 activation path: csrc/bf16.hip)
+int msl_stem_conv_fwd_bf16(const float* x, const float* w, void* y_bf16, double* partials, int N, int Cin, int D,
+                           int H, int W, int sd, int sh, int sw, void* stream) {
+  return stem_fwd_impl(x, w, y_bf16, partials, N, Cin, D, H, W, sd, sh, sw, true, stream);
 }
 
 size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin) {

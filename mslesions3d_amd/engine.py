@@ -267,6 +267,8 @@ class Engine:
         return self.arena
 
     def plan_for(self, x, need_grad):
+        if getattr(self.model, "compute_dtype", "f32") == "bf16" and not need_grad:
+            return self._plan_bf16(x)
         key = (x.shape[0], tuple(x.shape[2:]), x.device, need_grad)
         p = self.plans.get(key)
         if p is None:
@@ -371,6 +373,10 @@ class Engine:
                                       "model and the input to 'cuda'")
         L = _lib.load()
         m = self.model
+        if getattr(m, "compute_dtype", "f32") == "bf16":
+            if training:
+                raise NotImplementedError("the bf16 activation path covers inference (eval mode) only; train in fp32")
+            return self._forward_bf16(x, want_features=want_features, nan_check=nan_check)
         x = x.contiguous().float()
         self.ensure_arena(x.device)
         pl = self.plan_for(x, need_grad)
@@ -483,6 +489,98 @@ class Engine:
         if self.multi_stream:
             self._fork(pl, "fwd_heads_done", stH, st)
         if nan_check:  # the fused training step lets the loss kernel set the flag instead (it reads both tensors anyway)
+            _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
+            _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
+        if want_features:
+            return pl.locs, pl.scores, out_feats
+        return pl.locs, pl.scores
+
+    # ------------------------------------------------------------------------------------------------
+    def _plan_bf16(self, x):
+        """Buffers of the bf16 inference pass for this input shape (BASELINE configs[3])."""
+        key = ("bf16", x.shape[0], tuple(x.shape[2:]), x.device)
+        pl = self.plans.get(key)
+        if pl is not None:
+            return pl
+        L = _lib.load()
+        m, specs = self.model, self.layer_specs
+
+        class _P:
+            pass
+        pl = _P()
+        N, dev = x.shape[0], x.device
+        pl.N, pl.in_dims = N, tuple(x.shape[2:])
+        pl.dims, cur = [], tuple(x.shape[2:])
+        for sp in specs:
+            cur = tuple(conv_out(d, s) for d, s in zip(cur, sp["stride"]))
+            pl.dims.append(cur)
+        bf = dict(dtype=torch.bfloat16, device=dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        pl.y = [torch.empty((N, sp["cout"]) + pl.dims[i], **bf) for i, sp in enumerate(specs)]
+        pl.z = [None] + [torch.empty((N, specs[i]["cin"]) + pl.dims[i], **bf) for i in range(1, len(specs))]
+        pl.bn_y = [torch.zeros((BN_ROWS, sp["cout"]), **f32) for sp in specs]
+        pl.bn_z = [None] + [torch.zeros((BN_ROWS, specs[i]["cin"]), **f32) for i in range(1, len(specs))]
+        pl.part_y = [torch.empty(1, dtype=torch.float64, device=dev) for _ in specs]  # eval mode: no statistics
+        pl.part_z = [None] + [torch.empty(1, dtype=torch.float64, device=dev) for _ in specs[1:]]
+        pl.np_y, pl.np_z = [1] * len(specs), [None] + [1] * (len(specs) - 1)
+        pl.feat_ids = list(m.aspect_ratios.keys())
+        pl.prior_off, off = {}, 0
+        for f in pl.feat_ids:
+            pl.prior_off[f] = off
+            D, H, W = pl.dims[f]
+            off += D * H * W * m.boxes_per_location
+        pl.P = off
+        pl.fpad_cl = {f: torch.zeros((N,) + tuple(d + 2 for d in pl.dims[f]) + (specs[f]["cout"],), **bf) for f in pl.feat_ids}
+        pl.Wp = {f: torch.empty(L.msl_head_packed_weight_bf16_elems(specs[f]["cout"]), **bf) for f in pl.feat_ids}
+        pl.locs = torch.empty((N, pl.P, 6), **f32)
+        pl.scores = torch.empty((N, pl.P, m.n_classes), **f32)
+        pl.nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        pl.events, pl.generation, pl.saved_input, pl.need_grad, pl.trained_mode = {}, 0, None, False, False
+        self.plans[key] = pl
+        return pl
+
+    def _forward_bf16(self, x, want_features=False, nan_check=True):
+        """Eval-mode forward with bf16 activations in HBM (csrc/bf16.hip + the bf16 head kernel): fp32 input volume,
+        fp32 weights and BatchNorm vectors, bf16 everything in between, fp32 locs / scores out.  One stream."""
+        m, specs, feats = self.model, self.layer_specs, self.model.base.features
+        x = x.contiguous().float()
+        self.ensure_arena(x.device)
+        pl = self._plan_bf16(x)
+        pl.generation += 1
+        st = self._stream()
+        N = pl.N
+        _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
+        every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], 1, 1.0)]
+        for i in range(1, len(specs)):
+            every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], 1, 1.0), (feats[i].bn2, pl.bn_y[i], pl.part_y[i], 1, 1.0)]
+        self._finalize_all(pl, every, st, eval_mode=True)
+        D, H, W = pl.in_dims
+        self._k("stem_fwd", "msl_stem_conv_fwd_bf16", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), None, N,
+                specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        out_feats = {}
+        ncls = m.n_classes
+        for i in range(1, len(specs)):
+            sp, blk = specs[i], feats[i]
+            pd, ph, pw = pl.dims[i - 1]
+            D, H, W = pl.dims[i]
+            S = D * H * W
+            self._k(f"dw_fwd{i}", "msl_dwconv_fwd_bf16", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
+                    ptr(blk.conv1.weight), ptr(pl.z[i]), None, N, sp["cin"], pd, ph, pw, sp["stride"][0], st)
+            self._k(f"pw_fwd{i}", "msl_pwconv_fwd_bf16", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
+                    ptr(blk.conv2.weight), ptr(pl.y[i]), None, N, sp["cin"], sp["cout"], S, st)
+            if i in pl.fpad_cl:
+                plain = None
+                if want_features:
+                    plain = out_feats[i] = torch.empty((N, sp["cout"], D, H, W), dtype=torch.float32, device=x.device)
+                self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16", ptr(pl.y[i]), ptr(pl.bn_y[i][0]), ptr(pl.bn_y[i][1]),
+                        ptr(plain), ptr(pl.fpad_cl[i]), N, sp["cout"], D, H, W, st)
+                k = pl.feat_ids.index(i)
+                lc, cc = m.pred_convs.loc_convs[k], m.pred_convs.cl_convs[k]
+                self._k(f"head_pack{i}", "msl_head_pack_weights_bf16", ptr(lc.weight), ptr(cc.weight), ptr(pl.Wp[i]), sp["cout"],
+                        ncls, st)
+                self._k(f"head_fwd{i}", "msl_head_conv_fwd_bf16", ptr(pl.fpad_cl[i]), ptr(pl.Wp[i]), ptr(lc.bias), ptr(cc.bias),
+                        ptr(pl.locs), ptr(pl.scores), N, sp["cout"], D, H, W, pl.P, pl.prior_off[i], ncls, st)
+        if nan_check:
             _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
             _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
         if want_features:

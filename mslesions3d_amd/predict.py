@@ -28,6 +28,8 @@ def build_parser():
     p.add_argument('-sc', '--min_score', type=float, default=0.5)
     p.add_argument('-k', '--top_k', type=int, default=100)
     p.add_argument('-o', '--output_dir', type=str, default=r"../data/predictions/")
+    # not in the reference's CLI: bf16 activations for the eval forward (fp32 is the reference's precision)
+    p.add_argument('--dtype', type=str, choices=['f32', 'bf16'], default='f32')
     return p
 
 
@@ -65,6 +67,7 @@ def predict_example(args):
     dataset.setup(stage="predict_train" if args.predict_subset == "train" else "predict")
     model = LSSD3D.load_from_checkpoint(args.model_path, min_score=args.min_score).to("cuda").eval()
     model.top_k, model.min_score = args.top_k, args.min_score  # predict.py:259-260
+    model.compute_dtype = getattr(args, "dtype", "f32")
     metrics = {"0.5": {}, "0.1": {}}
     for batch in dataset.predict_dataloader():
         boxes, labels, scores = model.predict_step(batch, 0)

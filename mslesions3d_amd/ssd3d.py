@@ -273,6 +273,9 @@ class LSSD3D(nn.Module):
         self._param_names = [n for n, _ in self.named_parameters()]
         self._det_ws = {}
         self._pred_programs = {}
+        # "f32" (the reference's precision) or "bf16": eval-mode passes keep the activations in HBM as bf16 (fp32 weights,
+        # BatchNorm vectors and accumulators; pointwise + head convolutions on bf16 MFMA) - BASELINE configs[3]
+        self.compute_dtype = "f32"
         self.use_predict_programs = True  # predict_step replays a recorded launch program (see _predict_replay)
 
         # Prior boxes (ssd3d.py:244).  The draw below keeps RNG parity with the reference's third dummy pass.
@@ -370,6 +373,8 @@ class LSSD3D(nn.Module):
         self._engine.ensure_arena(image.device)
         params = [p for _, p in self.named_parameters()]
         need_grad = self.training and torch.is_grad_enabled()
+        if self.compute_dtype not in ("f32", "bf16"):
+            raise ValueError(f"compute_dtype must be 'f32' or 'bf16', got {self.compute_dtype!r}")
         locs, classes_scores = _SSDFunction.apply(self, need_grad, image, *params)
         self._engine.check_nan(self._engine.plan_for(image, need_grad))
         return locs, classes_scores
@@ -518,7 +523,8 @@ class LSSD3D(nn.Module):
         self._ensure_device_state(dev)
         eng = self._engine
         eng.ensure_arena(dev)
-        key = (tuple(x.shape), _stream(), float(self.min_score), float(self.max_overlap), int(self.top_k), id(eng.arena))
+        key = (tuple(x.shape), _stream(), float(self.min_score), float(self.max_overlap), int(self.top_k), id(eng.arena),
+               self.compute_dtype)
         ent = self._pred_programs.get(key)
         if ent is None:
             buf = torch.empty_like(x)

@@ -1,4 +1,4 @@
-"""Inference path of BASELINE configs[3] (192^3, batch 2) in fp32: eval forward + decode + 3-D NMS (predict_step),
+"""Inference path of BASELINE configs[3] (192^3, batch 2) in fp32 or bf16 (--dtype): eval forward + decode + 3-D NMS (predict_step),
 timed.  Parity of this exact workload against the CPU oracle (keep-lists bit-exact, boxes within 1e-4) is
 tests/test_gpu_model.py::test_inference_192_end_to_end_matches_the_oracle.
 Usage (GPU box): python tools/bench_infer.py [--size 192] [--batch 2]"""
@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--size", type=int, default=192)
 ap.add_argument("--batch", type=int, default=2)
 ap.add_argument("--steps", type=int, default=30)
+ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32")
 args = ap.parse_args()
 
 from mslesions3d_amd.ssd3d import LSSD3D  # noqa: E402
@@ -31,6 +32,7 @@ x, boxes, labels = make_batch_on_device(args.batch, size, dev, 1, seed=3)
 for _ in range(3):
     tr.step(x, boxes, labels)
 model.eval()
+model.compute_dtype = args.dtype
 kw = dict(min_score=0.3, max_overlap=0.3, top_k=50)
 with torch.no_grad():
     locs, scores = model(x)
@@ -49,7 +51,7 @@ for _ in range(args.steps):
 torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 print(f"predict_step: {dt / args.steps * 1e3:.2f} ms per batch of {args.batch} -> {args.batch * args.steps / dt:.0f} volumes/s, "
-      f"{nb / dt:.0f} boxes/s (fp32, host sync per batch for the detection counts)")
+      f"{nb / dt:.0f} boxes/s ({args.dtype}, host sync per batch for the detection counts)")
 
 # parity of this exact workload against the CPU oracle: tests/test_gpu_model.py::test_inference_192_end_to_end_matches_the_oracle
 # (the oracle is test infrastructure and is not imported from tools/)
