@@ -1,6 +1,7 @@
 """Headline benchmark: training volumes/s of the 3D-SSD step at 128^3, batch 4 per GPU, fp32 (BASELINE.json).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --dtype bf16          # BASELINE configs[2]: the same step with bf16 activations
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -34,6 +35,9 @@ def parse():
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--batch", type=int, default=4, help="volumes per GPU")
     ap.add_argument("--channels", type=int, default=1)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: the headline configuration (BASELINE configs[1]); bf16: activations and activation gradients "
+                         "stored as bf16, fp32 weights / accumulators / optimiser (BASELINE configs[2])")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=25)  # ~10 s of CPU work
     ap.add_argument("--no-aggregate", action="store_true",
@@ -104,6 +108,7 @@ def main():
     torch.manual_seed(970205)  # train.py:61
     model = LSSD3D(n_classes=2, input_channels=args.channels, input_size=size, threshold=[0.1, 0.2], alpha=1.0, lr=1e-3,
                    batch_size=args.batch).to(dev).train()
+    model.compute_dtype = args.dtype
     model._ensure_device_state(dev)
     model._engine.ensure_arena(dev)
     broadcast_model(model)
@@ -199,45 +204,68 @@ def main():
         C1 = 32
         d0 = pl.dims[0]
         d1 = pl.dims[1]
-        alg_bytes = 4.0 * (args.batch * C1 * (d0[0] * d0[1] * d0[2] + d1[0] * d1[1] * d1[2]) + C1 * 27)
+        esz = 4.0 if args.dtype == "f32" else 2.0  # bytes per activation element in HBM
+        alg_bytes = esz * args.batch * C1 * (d0[0] * d0[1] * d0[2] + d1[0] * d1[1] * d1[2]) + 4.0 * C1 * 27
         ms = prof.get("dw_fwd1", [])
         avg_ms = sum(ms) / max(len(ms), 1)
         achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if ms else None
-        variant = _lib.load().msl_dwconv_fwd_variant(args.batch, C1, *d0, 2)
-        dw1_kernel = {3: "dw_s2_wave_kernel<4,5,4>", 1: "dw_fwd_stream_kernel<2,1,4,0>"}.get(variant, f"dwconv variant {variant}")
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "dw_fwd1_traffic.json")
-        if os.path.exists(tpath):  # PMC bytes per launch of THIS kernel (tools/summarize_profiles.py), else null
+        if args.dtype == "f32":
+            variant = _lib.load().msl_dwconv_fwd_variant(args.batch, C1, *d0, 2)
+            dw1_kernel = {3: "dw_s2_wave_kernel<4,5,4>", 1: "dw_fwd_stream_kernel<2,1,4,0>"}.get(variant, f"dwconv variant {variant}")
+        else:
+            dw1_kernel = "dw_fwd_bf16_kernel<2>"
+        # committed rocprofv3 measurements of THIS kernel on this workload (tools/summarize_profiles.py): PMC bytes per
+        # launch and the kernel-trace duration.  Constants of the named profile, not something this run measured.
+        traffic, traffic_src, frac_rocprof, agg_rocprof = None, None, None, None
+        tpath = os.path.join(ROOT, "profiles", "dw_fwd1_traffic.json" if args.dtype == "f32" else "dw_fwd1_traffic_bf16.json")
+        default_shape = args.size == 128 and args.batch == 4 and args.channels == 1
+        if os.path.exists(tpath) and default_shape:
             tj = json.load(open(tpath))
             if tj.get("kernel", "").replace(" ", "") == dw1_kernel:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = f"profiles/{tj.get('profile')}_pmc_summary.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of this " \
+                              f"command, committed; not measured by this run)"
+                if tj.get("avg_launch_us_rocprof"):
+                    us = float(tj["avg_launch_us_rocprof"])
+                    frac_rocprof = {"frac": round(alg_bytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "avg_launch_us": us,
+                                    "profile": f"profiles/{tj.get('profile')}_kernel_stats.csv"}
+                agg_rocprof = tj.get("depthwise_fwd_all_layers_rocprof")
         out = {
             "metric": "training volumes/sec at 128^3 batch-4 (fwd+loss+bwd+Adam), data-parallel over N MI355X",
             "value": round(value, 2), "unit": "volumes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.size}^3 synthetic volumes, batch {args.batch}/GPU, {args.channels} channel(s), fp32, "
-                                   f"SSD3D+MobileNet3D full train step (BASELINE configs[1]/[2] shape)",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.size}^3 synthetic volumes, batch {args.batch}/GPU, {args.channels} channel(s), "
+                                   + ("fp32, SSD3D+MobileNet3D full train step (BASELINE configs[1])" if args.dtype == "f32" else
+                                      "bf16 activations + activation gradients / fp32 weights, accumulators and Adam, "
+                                      "SSD3D+MobileNet3D full train step (BASELINE configs[2])"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "priors": pl.P,
                        "last_loss": {"conf": conf, "loc": loc, "n_positives": npos}},
             "roofline": {"bound": "hbm", "kernel": dw1_kernel + " (depthwise 3x3x3 s2 forward, block 1)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
-                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_basis": "HIP-event pair around the launch inside the timed steps (includes the dispatch gap; "
+                                       "conservative against the kernel-trace duration in frac_rocprof)",
+                         "frac_rocprof": frac_rocprof,
+                         "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": len(ms)},
+            "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MSL_")},
         }
         if dw_all and all(dw_all.get(f"dw_fwd{i}") for i in range(1, 8)):
             # block i reads (N, C_i, dims[i-1]) and writes (N, C_i, dims[i]) once, plus its taps
             chans = [32, 64, 128, 128, 256, 256, 512]
             vol = lambda d: d[0] * d[1] * d[2]
-            lay_b = [4.0 * (args.batch * c * (vol(pl.dims[i]) + vol(pl.dims[i + 1])) + c * 27) for i, c in enumerate(chans)]
+            lay_b = [esz * args.batch * c * (vol(pl.dims[i]) + vol(pl.dims[i + 1])) + 4.0 * c * 27 for i, c in enumerate(chans)]
             lay_us = [1e3 * sum(dw_all[f"dw_fwd{i}"]) / len(dw_all[f"dw_fwd{i}"]) for i in range(1, 8)]
             tot_gbs = sum(lay_b) / (sum(lay_us) * 1e-6) / 1e9
             agg = {"algorithmic_bytes": sum(lay_b),
                    "in_step_event_pairs": {"sum_launch_us": round(sum(lay_us), 2), "achieved": round(tot_gbs, 1),
                                            "frac": round(tot_gbs / HBM_PEAK_GBS, 4),
                                            "per_layer_us": [round(u, 2) for u in lay_us]},
-                   "note": "SURVEY 8(d): all seven depthwise forwards, 222.7 MB / sum(t) / peak.  in_step_event_pairs: a HIP "
+                   "rocprof_kernel_trace": agg_rocprof,
+                   "note": "SURVEY 8(d): all seven depthwise forwards, algorithmic bytes / sum(t) / peak, three accountings "
+                           "under fixed keys.  rocprof_kernel_trace: kernel durations of the committed profile (null when "
+                           "this is not the profiled shape).  in_step_event_pairs: a HIP "
                            "event pair around each of the seven launches inside the replayed step (20-step pass after "
                            "the timed region; each pair adds ~5 us of event/dispatch overhead to a ~5 us kernel).  "
                            "back_to_back: each launch re-issued 50x alone from the recorded program on the step's "

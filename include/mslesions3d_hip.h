@@ -193,6 +193,31 @@ int msl_head_pack_weights_bf16(const float* loc_w, const float* cl_w, void* Wp, 
 int msl_head_conv_fwd_bf16(const void* a_cl, const void* Wp, const float* loc_b, const float* cl_b, float* locs,
                            float* scores, int N, int C, int D, int H, int W, int Ptot, int prior_off, int ncls,
                            void* stream);
+/* ... and the backward kernels of the bf16 training step (BASELINE configs[2]); gradients of activations are bf16 too,
+ * weight gradients and all reductions fp32 / fp64 (same partial-sum layouts as the fp32 kernels, folded by
+ * msl_grad_reduce_batch / msl_bn_bwd_finalize): */
+int msl_pwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, int Cin, int Cout, int S, void* stream);
+int msl_pwconv_bwd_weight_bf16_nslabs(int N, int Cin, int Cout, int S);
+int msl_pwconv_bwd_weight_slabs_bf16(const void* dy, const void* z, const float* in_scale, const float* in_shift, float* out,
+                                     int N, int Cin, int Cout, int S, void* stream);
+int msl_dwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, int C, int D, int H, int W, int stride,
+                             int accumulate, void* stream);
+int msl_dwconv_bwd_weight_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift, double* partials,
+                               int N, int C, int D, int H, int W, int stride, void* stream);
+int msl_bn_relu_bwd_bf16_num_partials(int N, int S);
+int msl_bn_relu_bwd_reduce_bf16(const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, double* partials, int N, int C, int S, void* stream);
+int msl_bn_relu_bwd_apply_bf16(const void* g, const void* y, const float* vec, void* dy, int N, int C, int S, void* stream);
+int msl_bn_relu_bwd_fused_bf16(const void* g, const void* y, const float* vec, float* dgamma, float* dbeta, void* dy, int N,
+                               int C, int S, void* stream);
+int msl_head_conv_bwd_data_bf16(const float* dO_pad, const float* Wb, void* g_a_bf16, int N, int C, int D, int H, int W,
+                                int ncls, void* stream);
+int msl_head_conv_bwd_weight_bf16(const float* dO_pad, const void* a_cl, float* dloc_w, float* dcl_w, float* dloc_b,
+                                  float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls,
+                                  void* stream);
+int msl_stem_conv_bwd_weight_bnapply_bf16(const void* g, const void* yraw, const float* bn_vec, const float* x, float* dw,
+                                          float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
+                                          void* stream);
 
 /* ---- priors, box math, matching, MultiBox loss : ssd3d.py:286-342, utils.py:42-149, ssd3d.py:741-941 ------- */
 int msl_make_priors(float* out, int row_off, int D0, int D1, int D2, double scale, int boxes_per_location,

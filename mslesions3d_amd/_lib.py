@@ -81,6 +81,18 @@ _SIGNATURES = {
     "msl_head_packed_weight_bf16_elems": (_Z, [_I]),
     "msl_head_pack_weights_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
     "msl_head_conv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_pwconv_bwd_data_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_pwconv_bwd_weight_bf16_nslabs": (_I, [_I, _I, _I, _I]),
+    "msl_pwconv_bwd_weight_slabs_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_data_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_weight_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_bn_relu_bwd_bf16_num_partials": (_I, [_I, _I]),
+    "msl_bn_relu_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_bn_relu_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_bn_relu_bwd_fused_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_head_conv_bwd_data_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_head_conv_bwd_weight_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_stem_conv_bwd_weight_bnapply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_make_priors": (_I, [_P, _I, _I, _I, _I, _D, _I, _P]),
     "msl_box_transform": (_I, [_P, _P, _P, _I, _I, _P]),
     "msl_iou_matrix": (_I, [_P, _P, _P, _I, _I, _I, _P]),

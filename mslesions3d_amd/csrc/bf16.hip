@@ -23,12 +23,14 @@ typedef u16 u16x4 __attribute__((ext_vector_type(4)));
 // (h, w) column.  256 threads = TH * TW.
 constexpr int DW_TD = 2, DW_TH = 8, DW_TW = 32;
 
+// flip != 0: taps reversed (w[26 - k]) - the stride-1 bwd-data pass; accumulate != 0: y += result (the feature-map
+// gradient already holds the heads' share).
 template <int STRIDE>
 __global__ __launch_bounds__(256) void dw_fwd_bf16_kernel(const u16* __restrict__ x, const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift, const float* __restrict__ w,
                                                           u16* __restrict__ y, double* __restrict__ partials, int C, int D,
                                                           int H, int W, int OD, int OH, int OW, int tiles_h, int tiles_w,
-                                                          int NP) {
+                                                          int NP, int flip, int accumulate) {
   constexpr int ID = (DW_TD - 1) * STRIDE + 3, IH = (DW_TH - 1) * STRIDE + 3, IW = (DW_TW - 1) * STRIDE + 3;
   __shared__ float tile[ID * IH * IW];
   __shared__ double scratch[8];
@@ -72,7 +74,7 @@ __global__ __launch_bounds__(256) void dw_fwd_bf16_kernel(const u16* __restrict_
   }
   float wt[27];
 #pragma unroll
-  for (int k = 0; k < 27; ++k) wt[k] = w[c * 27 + k];
+  for (int k = 0; k < 27; ++k) wt[k] = w[c * 27 + (flip ? 26 - k : k)];
   __syncthreads();
   const int lw = threadIdx.x % DW_TW, lh = threadIdx.x / DW_TW;
   const int ow = ow0 + lw, oh = oh0 + lh;
@@ -89,7 +91,9 @@ __global__ __launch_bounds__(256) void dw_fwd_bf16_kernel(const u16* __restrict_
         for (int kw = 0; kw < 3; ++kw)
           acc = fmaf(wt[kd * 9 + kh * 3 + kw], tile[((d * STRIDE + kd) * IH + lh * STRIDE + kh) * IW + lw * STRIDE + kw], acc);
     if (od < OD && oh < OH && ow < OW) {
-      y[((size_t)nc * OD + od) * OH * OW + (size_t)oh * OW + ow] = msl::f2bf(acc);
+      u16* yo = y + ((size_t)nc * OD + od) * OH * OW + (size_t)oh * OW + ow;
+      if (accumulate) acc += msl::bf2f(*yo);
+      *yo = msl::f2bf(acc);
       s += (double)acc;
       q += (double)acc * (double)acc;
     }
@@ -112,7 +116,8 @@ __global__ __launch_bounds__(256) void dw_fwd_bf16_kernel(const u16* __restrict_
 // activation chunk is transposed on its way into LDS).  4 waves = 2 x 2 tiles of 32 x 32.
 constexpr int PB_BM = 64, PB_BN = 64, PB_BK = 32, PB_LD = PB_BK + 8;  // 80-byte rows: 16-byte aligned fragments
 
-template <bool STATS>
+// TRANS_W: weight element (m, k) = Wt[k * M + m] (bwd-data: M = Cin, K = Cout, the same weights read transposed).
+template <bool STATS, bool TRANS_W = false>
 __global__ __launch_bounds__(256) void pw_fwd_bf16_kernel(const u16* __restrict__ Z, const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift, const float* __restrict__ Wt,
                                                           u16* __restrict__ Y, double* __restrict__ partials, int M, int K,
@@ -131,10 +136,15 @@ __global__ __launch_bounds__(256) void pw_fwd_bf16_kernel(const u16* __restrict_
   f32x16 acc = {0};
   for (int k0 = 0; k0 < K; k0 += PB_BK) {
     float wv8[8];
-    {
+    if (!TRANS_W) {
       const int row = m0 + wrow < M ? m0 + wrow : 0;
       const float4 a = *reinterpret_cast<const float4*>(Wt + (size_t)row * K + k0 + wk8);
       const float4 b = *reinterpret_cast<const float4*>(Wt + (size_t)row * K + k0 + wk8 + 4);
+      wv8[0] = a.x; wv8[1] = a.y; wv8[2] = a.z; wv8[3] = a.w; wv8[4] = b.x; wv8[5] = b.y; wv8[6] = b.z; wv8[7] = b.w;
+    } else {  // thread -> k row xk, 8 consecutive m (contiguous in memory); M % 8 == 0
+      const int mm = m0 + xc8 < M ? m0 + xc8 : 0;
+      const float4 a = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + xk) * M + mm);
+      const float4 b = *reinterpret_cast<const float4*>(Wt + (size_t)(k0 + xk) * M + mm + 4);
       wv8[0] = a.x; wv8[1] = a.y; wv8[2] = a.z; wv8[3] = a.w; wv8[4] = b.x; wv8[5] = b.y; wv8[6] = b.z; wv8[7] = b.w;
     }
     float xv8[8];
@@ -157,10 +167,15 @@ __global__ __launch_bounds__(256) void pw_fwd_bf16_kernel(const u16* __restrict_
     }
     __syncthreads();  // the previous chunk has been consumed
     {
-      u16x8 p;
+      if (!TRANS_W) {
+        u16x8 p;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) p[i] = msl::f2bf(wv8[i]);
-      *reinterpret_cast<u16x8*>(&Ws[wrow * PB_LD + wk8]) = p;
+        for (int i = 0; i < 8; ++i) p[i] = msl::f2bf(wv8[i]);
+        *reinterpret_cast<u16x8*>(&Ws[wrow * PB_LD + wk8]) = p;
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) Ws[(xc8 + i) * PB_LD + xk] = msl::f2bf(wv8[i]);
+      }
 #pragma unroll
       for (int i = 0; i < 8; ++i) Xs[(xc8 + i) * PB_LD + xk] = msl::f2bf(xv8[i]);
     }
@@ -213,6 +228,320 @@ __global__ __launch_bounds__(256) void materialize_bf16_kernel(const u16* __rest
   *reinterpret_cast<u16x8*>(pad_cl + pos * C + c8) = o;
 }
 
+// ---- pointwise weight gradient -------------------------------------------------------------------------------------
+// dW[co][ci] = sum over (n, p) of dY[n][co][p] * act(Z[n][ci][p]): positions are the MFMA K dimension and the contiguous
+// axis of both operands, so lane (r, h) of v_mfma_f32_32x32x16_bf16 takes its 8 consecutive positions with one 16-byte
+// load per operand row - no transposition, no LDS in the loop.  Same decomposition and slab layout as the fp32 kernel
+// (pwconv.hip pw_bww_wave_kernel): wave = (32*MT) x 32 tile, 64-position chunks, 4 waves interleave chunks and meet in
+// LDS once; [nslabs][Cout][Cin] fp32 slabs folded by msl_grad_reduce_batch.
+template <int MT, bool AFFINE>
+__global__ __launch_bounds__(256) void pw_bww_bf16_kernel(const u16* __restrict__ dY, const u16* __restrict__ Z,
+                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                          float* __restrict__ out, int Cout, int Cin, int S, int chunks_per_img,
+                                                          int total_chunks, int chunks_per_block) {
+  __shared__ __align__(16) float red[4 * MT * 1024];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
+  const int ks = blockIdx.x;
+  const int tiles_n = Cin / 32;
+  const int tm = blockIdx.y / tiles_n, tn = blockIdx.y % tiles_n;
+  const int m0 = tm * 32 * MT, n0 = tn * 32;
+  const int ch_lo = ks * chunks_per_block, ch_hi = min(total_chunks, ch_lo + chunks_per_block);
+  const int mine = max(0, (ch_hi - ch_lo - wv + 3) / 4);
+  float sc = 1.f, sh = 0.f;
+  if (AFFINE) {
+    sc = in_scale[n0 + c];
+    sh = in_shift[n0 + c];
+  }
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) acc[mt] = (f32x16){0};
+  for (int i = 0; i < mine; ++i) {
+    const int ch = ch_lo + wv + 4 * i;
+    const int n = ch / chunks_per_img, s0 = (ch - n * chunks_per_img) * 64 + 8 * h;
+    u16x8 a[MT][4], b[4];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const u16* p = dY + ((size_t)n * Cout + m0 + mt * 32 + c) * S + s0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[mt][j] = *reinterpret_cast<const u16x8*>(p + 16 * j);
+    }
+    const u16* q = Z + ((size_t)n * Cin + n0 + c) * S + s0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const u16x8*>(q + 16 * j);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      u16x8 bv = b[j];
+      if (AFFINE) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = msl::f2bf(msl::act(msl::bf2f(bv[e]), sc, sh));
+      }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt)
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[mt][j]), __builtin_bit_cast(bf16x8, bv),
+                                                          acc[mt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wv * MT + mt) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h) * 32 + c] = acc[mt][r];
+  __syncthreads();
+  float* dst = out + (size_t)ks * Cout * Cin;
+#pragma unroll
+  for (int e = 0; e < MT; ++e) {
+    const int q4 = threadIdx.x + e * 256;
+    const int row = q4 >> 3, col = (q4 & 7) * 4;
+    float4 v = *reinterpret_cast<const float4*>(&red[row * 32 + col]);
+#pragma unroll
+    for (int w2 = 1; w2 < 4; ++w2) {
+      const float4 t = *reinterpret_cast<const float4*>(&red[(w2 * MT * 32 + row) * 32 + col]);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    *reinterpret_cast<float4*>(dst + (size_t)(m0 + row) * Cin + n0 + col) = v;
+  }
+}
+
+// Any-shape fallback of the pointwise weight gradient (position counts that are no multiple of 64, e.g. the 2^3 maps of a
+// 64^3 input): workgroup = 16 x 16 tile of dW, positions staged through LDS 64 at a time; one slab.
+template <bool AFFINE>
+__global__ __launch_bounds__(256) void pw_bww_bf16_any_kernel(const u16* __restrict__ dY, const u16* __restrict__ Z,
+                                                              const float* __restrict__ in_scale,
+                                                              const float* __restrict__ in_shift, float* __restrict__ out,
+                                                              int N, int Cout, int Cin, int S) {
+  __shared__ float sy[16][65], sz[16][65];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int co0 = blockIdx.y * 16, ci0 = blockIdx.x * 16;
+  float acc = 0.f;
+  for (int n = 0; n < N; ++n)
+    for (int p0 = 0; p0 < S; p0 += 64) {
+      __syncthreads();
+      for (int e = threadIdx.x; e < 16 * 64; e += 256) {
+        const int r = e >> 6, c = e & 63, p = p0 + c;
+        float a = 0.f, b = 0.f;
+        if (p < S) {
+          if (co0 + r < Cout) a = msl::bf2f(dY[((size_t)n * Cout + co0 + r) * S + p]);
+          if (ci0 + r < Cin) {
+            b = msl::bf2f(Z[((size_t)n * Cin + ci0 + r) * S + p]);
+            if (AFFINE) b = msl::bf2f(msl::f2bf(fmaxf(fmaf(b, in_scale[ci0 + r], in_shift[ci0 + r]), 0.f)));
+          }
+        }
+        sy[r][c] = a;
+        sz[r][c] = b;
+      }
+      __syncthreads();
+#pragma unroll 16
+      for (int c = 0; c < 64; ++c) acc = fmaf(sy[ty][c], sz[tx][c], acc);
+    }
+  if (co0 + ty < Cout && ci0 + tx < Cin) out[(size_t)(co0 + ty) * Cin + ci0 + tx] = acc;
+}
+
+// ---- depthwise, stride-2 bwd-data ------------------------------------------------------------------------------------
+// g_in[i] = sum over taps k with (i + 1 - k) even of w[k] * dy[(i + 1 - k) / 2].  Workgroup = (n, c) x an input tile of
+// 4 x 8 x 64 voxels; the dy tile it touches (3 x 5 x 33) is staged in LDS as fp32.
+constexpr int DB_TD = 4, DB_TH = 8, DB_TW = 64;
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_bf16_kernel(const u16* __restrict__ dy, const float* __restrict__ w,
+                                                                  u16* __restrict__ g_in, int C, int D, int H, int W, int OD,
+                                                                  int OH, int OW, int tiles_h, int tiles_w, int accumulate) {
+  constexpr int LD = DB_TD / 2 + 1, LH = DB_TH / 2 + 1, LW = DB_TW / 2 + 1;
+  __shared__ float tile[LD * LH * LW];
+  const int nc = blockIdx.y, c = nc % C;
+  const int t = blockIdx.x;
+  const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, td = t / (tiles_w * tiles_h);
+  const int id0 = td * DB_TD, ih0 = th * DB_TH, iw0 = tw * DB_TW;
+  // outputs o with 2o - 1 + k = i for i in the tile: o from id0 / 2 (i = id0, k = 1; id0 even) to (id0 + TD) / 2
+  const int od0 = id0 >> 1, oh0 = ih0 >> 1, ow0 = iw0 >> 1;
+  const u16* dc = dy + (size_t)nc * OD * OH * OW;
+  for (int e = threadIdx.x; e < LD * LH * LW; e += 256) {
+    const int lw = e % LW, lh = (e / LW) % LH, ld = e / (LW * LH);
+    const int od = od0 + ld, oh = oh0 + lh, ow = ow0 + lw;
+    const bool ok = od < OD && oh < OH && ow < OW;
+    tile[e] = ok ? msl::bf2f(dc[((size_t)od * OH + oh) * OW + ow]) : 0.f;
+  }
+  float wt[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wt[k] = w[c * 27 + k];
+  __syncthreads();
+  // thread -> (h, w pair): 8 x 32 pairs; 2 voxels along w, all TD planes
+  const int lwp = threadIdx.x % 32, lh = threadIdx.x / 32;
+  u16* gc = g_in + (size_t)nc * D * H * W;
+#pragma unroll
+  for (int d = 0; d < DB_TD; ++d) {
+    const int id = id0 + d, ih = ih0 + lh;
+#pragma unroll
+    for (int ww = 0; ww < 2; ++ww) {
+      const int iw = iw0 + 2 * lwp + ww;
+      float acc = 0.f;
+#pragma unroll
+      for (int kd = 0; kd < 3; ++kd) {
+        const int tdd = d + 1 - kd;           // (id + 1 - kd) - id0, id0 even
+        if (tdd < 0 || (tdd & 1)) continue;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+          const int thh = lh + 1 - kh;
+          if (thh < 0 || (thh & 1)) continue;
+#pragma unroll
+          for (int kw = 0; kw < 3; ++kw) {
+            const int tww = 2 * lwp + ww + 1 - kw;
+            if (tww < 0 || (tww & 1)) continue;
+            acc = fmaf(wt[kd * 9 + kh * 3 + kw], tile[((tdd >> 1) * LH + (thh >> 1)) * LW + (tww >> 1)], acc);
+          }
+        }
+      }
+      if (id < D && ih < H && iw < W) {
+        u16* go = gc + ((size_t)id * H + ih) * W + iw;
+        if (accumulate) acc += msl::bf2f(*go);
+        *go = msl::f2bf(acc);
+      }
+    }
+  }
+}
+
+// ---- depthwise weight gradient ---------------------------------------------------------------------------------------
+// dW[c][k] = sum over (n, o) of dz[n][c][o] * act(x[n][c][o*s - 1 + k]); the activated input tile is staged exactly as in the
+// forward kernel, a thread multiplies its TD outputs' dz against the 27 taps, and the workgroup's 27 sums go out as fp64
+// partials [C*27][NP] (folded by msl_grad_reduce_batch kind 1).
+template <int STRIDE>
+__global__ __launch_bounds__(256) void dw_bww_bf16_kernel(const u16* __restrict__ dz, const u16* __restrict__ x,
+                                                          const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                          double* __restrict__ partials, int C, int D, int H, int W, int OD,
+                                                          int OH, int OW, int tiles_h, int tiles_w, int NP) {
+  constexpr int ID = (DW_TD - 1) * STRIDE + 3, IH = (DW_TH - 1) * STRIDE + 3, IW = (DW_TW - 1) * STRIDE + 3;
+  __shared__ float tile[ID * IH * IW];
+  __shared__ float wsum[4][27];
+  const int nc = blockIdx.y, c = nc % C, n = nc / C;
+  const int t = blockIdx.x;
+  const int tw = t % tiles_w, th = (t / tiles_w) % tiles_h, td = t / (tiles_w * tiles_h);
+  const int od0 = td * DW_TD, oh0 = th * DW_TH, ow0 = tw * DW_TW;
+  const int id0 = od0 * STRIDE - 1, ih0 = oh0 * STRIDE - 1, iw0 = ow0 * STRIDE - 1;
+  const bool affine = in_scale != nullptr;
+  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+  const u16* xc = x + (size_t)nc * D * H * W;
+  for (int e = threadIdx.x; e < ID * IH * IW; e += 256) {
+    const int lw = e % IW, lh = (e / IW) % IH, ld = e / (IW * IH);
+    const int id = id0 + ld, ih = ih0 + lh, iw = iw0 + lw;
+    const bool ok = id >= 0 && id < D && ih >= 0 && ih < H && iw >= 0 && iw < W;
+    float v = msl::bf2f(xc[ok ? ((size_t)id * H + ih) * W + iw : 0]);
+    if (affine) v = msl::act(v, sc, sh);
+    tile[e] = ok ? v : 0.f;
+  }
+  __syncthreads();
+  const int lw = threadIdx.x % DW_TW, lh = threadIdx.x / DW_TW;
+  const int ow = ow0 + lw, oh = oh0 + lh;
+  float s[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) s[k] = 0.f;
+#pragma unroll
+  for (int d = 0; d < DW_TD; ++d) {
+    const int od = od0 + d;
+    const bool ok = od < OD && oh < OH && ow < OW;
+    const float g = ok ? msl::bf2f(dz[((size_t)nc * OD + (ok ? od : 0)) * OH * OW + (size_t)(ok ? oh : 0) * OW + (ok ? ow : 0)]) : 0.f;
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd)
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw)
+          s[kd * 9 + kh * 3 + kw] = fmaf(g, tile[((d * STRIDE + kd) * IH + lh * STRIDE + kh) * IW + lw * STRIDE + kw], s[kd * 9 + kh * 3 + kw]);
+  }
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < 27; ++k) {
+    const float v = msl::wave_sum(s[k]);
+    if (lane == 0) wsum[wv][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 27) {
+    const int p = n * gridDim.x + blockIdx.x;
+    const double tot = ((double)wsum[0][threadIdx.x] + (double)wsum[1][threadIdx.x]) + ((double)wsum[2][threadIdx.x] + (double)wsum[3][threadIdx.x]);
+    partials[((size_t)c * 27 + threadIdx.x) * NP + p] = tot;
+  }
+}
+
+// ---- BatchNorm + ReLU backward ---------------------------------------------------------------------------------------
+// gm = g * [fma(y, scale, shift) > 0];  dbeta = sum gm;  dgamma = sum gm * xhat;  dy = scale * (gm - c1 - xhat * c2),
+// c1 = dbeta / count, c2 = dgamma / count (same algebra and vectors as the fp32 kernels of bn.hip).
+constexpr int BB_CHUNK = 4096;
+__global__ __launch_bounds__(256) void bn_relu_bwd_reduce_bf16_kernel(const u16* __restrict__ g, const u16* __restrict__ y,
+                                                                      const float* __restrict__ scale,
+                                                                      const float* __restrict__ shift,
+                                                                      const float* __restrict__ mean,
+                                                                      const float* __restrict__ invstd,
+                                                                      double* __restrict__ partials, int C, int S, int chunks) {
+  __shared__ double scratch[8];
+  const int ck = blockIdx.x, c = blockIdx.y, n = blockIdx.z;
+  const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+  const size_t base = ((size_t)n * C + c) * S;
+  const int lo = ck * BB_CHUNK, hi = min(S, lo + BB_CHUNK);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lo + threadIdx.x; i < hi; i += 256) {
+    const float yv = msl::bf2f(y[base + i]);
+    const float gm = fmaf(yv, sc, sh) > 0.f ? msl::bf2f(g[base + i]) : 0.f;
+    s1 += gm;
+    s2 += gm * ((yv - mu) * is);
+  }
+  const double t1 = msl::block_sum((double)s1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    const int NP = gridDim.z * chunks, p = n * chunks + ck;
+    partials[(size_t)c * NP + p] = t1;
+    partials[((size_t)C + c) * NP + p] = t2;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_bwd_apply_bf16_kernel(const u16* __restrict__ g, const u16* __restrict__ y,
+                                                                     const float* __restrict__ vec, u16* __restrict__ dy, int C,
+                                                                     int S) {
+  const int c = blockIdx.y, n = blockIdx.z;
+  const float sc = vec[c], sh = vec[C + c], mu = vec[2 * C + c], is = vec[3 * C + c], k1 = vec[4 * C + c], k2 = vec[5 * C + c];
+  const size_t base = ((size_t)n * C + c) * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < S; i += gridDim.x * 256) {
+    const float yv = msl::bf2f(y[base + i]);
+    const float gm = fmaf(yv, sc, sh) > 0.f ? msl::bf2f(g[base + i]) : 0.f;
+    dy[base + i] = msl::f2bf(sc * (gm - k1 - ((yv - mu) * is) * k2));
+  }
+}
+
+// one workgroup per channel: reduce, then apply (the channel's data is re-read from cache): small layers in one launch
+__global__ __launch_bounds__(256) void bn_relu_bwd_fused_bf16_kernel(const u16* __restrict__ g, const u16* __restrict__ y,
+                                                                     const float* __restrict__ vec, float* __restrict__ dgamma,
+                                                                     float* __restrict__ dbeta, u16* __restrict__ dy, int N,
+                                                                     int C, int S, double count) {
+  __shared__ double scratch[8];
+  __shared__ float coef[2];
+  const int c = blockIdx.x;
+  const float sc = vec[c], sh = vec[C + c], mu = vec[2 * C + c], is = vec[3 * C + c];
+  float s1 = 0.f, s2 = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * S;
+    for (int i = threadIdx.x; i < S; i += 256) {
+      const float yv = msl::bf2f(y[base + i]);
+      const float gm = fmaf(yv, sc, sh) > 0.f ? msl::bf2f(g[base + i]) : 0.f;
+      s1 += gm;
+      s2 += gm * ((yv - mu) * is);
+    }
+  }
+  const double t1 = msl::block_sum((double)s1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+    coef[0] = (float)(t1 / count);
+    coef[1] = (float)(t2 / count);
+  }
+  __syncthreads();
+  const float k1 = coef[0], k2 = coef[1];
+  for (int n = 0; n < N; ++n) {
+    const size_t base = ((size_t)n * C + c) * S;
+    for (int i = threadIdx.x; i < S; i += 256) {
+      const float yv = msl::bf2f(y[base + i]);
+      const float gm = fmaf(yv, sc, sh) > 0.f ? msl::bf2f(g[base + i]) : 0.f;
+      dy[base + i] = msl::f2bf(sc * (gm - k1 - ((yv - mu) * is) * k2));
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -233,10 +562,10 @@ int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_sh
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1)
     hipLaunchKernelGGL(dw_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)x, in_scale, in_shift, w, (u16*)y, partials,
-                       C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP);
+                       C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP, 0, 0);
   else
     hipLaunchKernelGGL(dw_fwd_bf16_kernel<2>, grid, dim3(256), 0, st, (const u16*)x, in_scale, in_shift, w, (u16*)y, partials,
-                       C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP);
+                       C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP, 0, 0);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -266,6 +595,138 @@ int msl_bn_relu_materialize_bf16(const void* y, const float* scale, const float*
   dim3 grid(msl::cdiv(D * H * W, 256), C / 8, N);
   hipLaunchKernelGGL(materialize_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, plain,
                      (u16*)pad_cl, C, D, H, W);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// ---- bf16 training step: backward kernels ----------------------------------------------------------------------------
+// dy (N,Cout,S) bf16 -> g_in (N,Cin,S) bf16 = W^T . dy   (bf16 MFMA, fp32 accumulate)
+int msl_pwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, int Cin, int Cout, int S, void* stream) {
+  if (N <= 0 || S <= 0 || Cout % PB_BK != 0 || Cin % 8 != 0) return MSL_ERR_ARG;
+  dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cin, PB_BM), N);
+  hipLaunchKernelGGL((pw_fwd_bf16_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, nullptr, nullptr,
+                     w, (u16*)g_in, nullptr, Cin, Cout, S);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// position split of msl_pwconv_bwd_weight_slabs_bf16 (number of [Cout][Cin] fp32 slabs; 1: the result itself)
+static inline bool bww_bf16_plan(int N, int Cin, int Cout, int S, int& mt, int& tiles, int& cpi, int& total, int& ks, int& cpb) {
+  if (S % 64 != 0 || Cin % 32 != 0 || Cout % 32 != 0) return false;
+  mt = (Cout % 64 == 0) ? 2 : 1;
+  tiles = (Cout / (32 * mt)) * (Cin / 32);
+  cpi = S / 64;
+  total = N * cpi;
+  ks = std::max(1, std::min(256 / std::max(1, tiles), total / 4));
+  cpb = msl::cdiv(total, ks);
+  ks = msl::cdiv(total, cpb);
+  return true;
+}
+int msl_pwconv_bwd_weight_bf16_nslabs(int N, int Cin, int Cout, int S) {
+  int mt, tiles, cpi, total, ks, cpb;
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || S <= 0) return MSL_ERR_ARG;
+  return bww_bf16_plan(N, Cin, Cout, S, mt, tiles, cpi, total, ks, cpb) ? ks : 1;
+}
+// dy (N,Cout,S), z (N,Cin,S) bf16 -> out = [nslabs][Cout][Cin] fp32 partial weight gradients (MFMA kernel when S % 64 == 0
+// and the channel counts are multiples of 32; a plain one-slab kernel otherwise)
+int msl_pwconv_bwd_weight_slabs_bf16(const void* dy, const void* z, const float* in_scale, const float* in_shift, float* out,
+                                     int N, int Cin, int Cout, int S, void* stream) {
+  int mt, tiles, cpi, total, ks, cpb;
+  if (N <= 0 || Cin <= 0 || Cout <= 0 || S <= 0) return MSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (!bww_bf16_plan(N, Cin, Cout, S, mt, tiles, cpi, total, ks, cpb)) {
+    dim3 g(msl::cdiv(Cin, 16), msl::cdiv(Cout, 16));
+    if (in_scale)
+      hipLaunchKernelGGL(pw_bww_bf16_any_kernel<true>, g, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, in_shift, out,
+                         N, Cout, Cin, S);
+    else
+      hipLaunchKernelGGL(pw_bww_bf16_any_kernel<false>, g, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, in_shift, out,
+                         N, Cout, Cin, S);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
+  dim3 grid(ks, tiles);
+#define MSL_BW(MT_, A_)                                                                                              \
+  hipLaunchKernelGGL((pw_bww_bf16_kernel<MT_, A_>), grid, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, \
+                     in_shift, out, Cout, Cin, S, cpi, total, cpb)
+  if (mt == 2) {
+    if (in_scale) MSL_BW(2, true); else MSL_BW(2, false);
+  } else {
+    if (in_scale) MSL_BW(1, true); else MSL_BW(1, false);
+  }
+#undef MSL_BW
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// dy (N,C,OD,OH,OW) bf16 -> g_in (N,C,D,H,W) bf16; accumulate != 0 adds into g_in
+int msl_dwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, int C, int D, int H, int W, int stride,
+                             int accumulate, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1) {  // the forward kernel with reversed taps
+    const int tiles_d = msl::cdiv(D, DW_TD), tiles_h = msl::cdiv(H, DW_TH), tiles_w = msl::cdiv(W, DW_TW);
+    dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
+    hipLaunchKernelGGL(dw_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)dy, nullptr, nullptr, w, (u16*)g_in, nullptr, C,
+                       D, H, W, D, H, W, tiles_h, tiles_w, 0, 1, accumulate);
+  } else {
+    const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+    const int tiles_d = msl::cdiv(D, DB_TD), tiles_h = msl::cdiv(H, DB_TH), tiles_w = msl::cdiv(W, DB_TW);
+    dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
+    hipLaunchKernelGGL(dw_bwd_data_s2_bf16_kernel, grid, dim3(256), 0, st, (const u16*)dy, w, (u16*)g_in, C, D, H, W, OD, OH, OW,
+                       tiles_h, tiles_w, accumulate);
+  }
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// dz (N,C,OD,OH,OW), x (N,C,D,H,W) bf16 (+ input affine) -> fp64 partials [C*27][NP], NP = msl_dwconv_fwd_bf16_num_partials
+int msl_dwconv_bwd_weight_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift, double* partials,
+                               int N, int C, int D, int H, int W, int stride, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || !partials) return MSL_ERR_ARG;
+  const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  const int tiles_d = msl::cdiv(OD, DW_TD), tiles_h = msl::cdiv(OH, DW_TH), tiles_w = msl::cdiv(OW, DW_TW);
+  const int NP = N * tiles_d * tiles_h * tiles_w;
+  dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
+  hipStream_t st = (hipStream_t)stream;
+  if (stride == 1)
+    hipLaunchKernelGGL(dw_bww_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)dz, (const u16*)x, in_scale, in_shift, partials,
+                       C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP);
+  else
+    hipLaunchKernelGGL(dw_bww_bf16_kernel<2>, grid, dim3(256), 0, st, (const u16*)dz, (const u16*)x, in_scale, in_shift, partials,
+                       C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_bn_relu_bwd_bf16_num_partials(int N, int S) { return N * msl::cdiv(S, BB_CHUNK); }
+
+// partials [2][C][NP] of (sum gm, sum gm * xhat); fold them with msl_bn_bwd_finalize (bn.hip), then _apply_bf16
+int msl_bn_relu_bwd_reduce_bf16(const void* g, const void* y, const float* scale, const float* shift, const float* mean,
+                                const float* invstd, double* partials, int N, int C, int S, void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
+  const int chunks = msl::cdiv(S, BB_CHUNK);
+  hipLaunchKernelGGL(bn_relu_bwd_reduce_bf16_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, (const u16*)g,
+                     (const u16*)y, scale, shift, mean, invstd, partials, C, S, chunks);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// vec = (6, C) rows [scale, shift, mean, invstd, c1, c2]; dy may alias g
+int msl_bn_relu_bwd_apply_bf16(const void* g, const void* y, const float* vec, void* dy, int N, int C, int S, void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_relu_bwd_apply_bf16_kernel, dim3(std::min(msl::cdiv(S, 1024), 64), C, N), dim3(256), 0, (hipStream_t)stream,
+                     (const u16*)g, (const u16*)y, vec, (u16*)dy, C, S);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// whole BatchNorm + ReLU backward of small layers in one launch (one workgroup per channel); vec rows 0-3 are read
+int msl_bn_relu_bwd_fused_bf16(const void* g, const void* y, const float* vec, float* dgamma, float* dbeta, void* dy, int N,
+                               int C, int S, void* stream) {
+  if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(bn_relu_bwd_fused_bf16_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const u16*)g, (const u16*)y, vec,
+                     dgamma, dbeta, (u16*)dy, N, C, S, (double)N * (double)S);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

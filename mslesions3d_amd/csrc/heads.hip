@@ -18,6 +18,9 @@
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));  // bf16 activation path
+typedef unsigned short hu16;
+typedef hu16 hu16x8 __attribute__((ext_vector_type(8)));
 
 // ---- weight packing ---------------------------------------------------------------------------
 // forward fragments: Wf[((cg*27 + tap)*MT + mt)*64 + lane] = Wall[co = mt*16 + (lane&15)][ci = 4*cg + (lane>>4)][tap]
@@ -236,9 +239,9 @@ __global__ __launch_bounds__(256) void head_grad_pack_kernel(const float* __rest
 }
 
 // g_a (N, C, S) = conv_transpose(dO, W).  grid (ceil(S/32), C/64, N); wave -> 16 input channels x 32 positions
-template <int MT>
+template <int MT, bool BF16OUT = false>
 __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ dO_pad,
-                                                            const float* __restrict__ Wb, float* __restrict__ g_a,
+                                                            const float* __restrict__ Wb, void* __restrict__ g_a_,
                                                             int C, int D, int H, int W) {
   const int n = blockIdx.z;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -283,10 +286,17 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     const int ci = ct * 16 + 4 * q + r;
-    float* dst = g_a + ((size_t)n * C + ci) * S;
+    const size_t rb = ((size_t)n * C + ci) * S;
     const int P0 = p0 + j, P1 = p0 + 16 + j;
-    if (P0 < S) dst[P0] = acc0[r];
-    if (P1 < S) dst[P1] = acc1[r];
+    if (BF16OUT) {
+      unsigned short* dst = reinterpret_cast<unsigned short*>(g_a_) + rb;
+      if (P0 < S) dst[P0] = msl::f2bf(acc0[r]);
+      if (P1 < S) dst[P1] = msl::f2bf(acc1[r]);
+    } else {
+      float* dst = reinterpret_cast<float*>(g_a_) + rb;
+      if (P0 < S) dst[P0] = acc0[r];
+      if (P1 < S) dst[P1] = acc1[r];
+    }
   }
 }
 
@@ -296,9 +306,10 @@ __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restr
 // partial-sum slabs (every position block costs one slab of the whole weight tensor), and a wave carries 9 instead of
 // 27 accumulator tiles.  The bias gradient sum_p dO[co][p] rides along as one more MFMA per step against a B operand
 // of ones (workgroups with blockIdx.y == 0 && kd == 0 only), so dO is not read a second time by a kernel of its own.
-template <int MT>
+// BF16CL: the feature map is the bf16 channels-last copy (N, D+2, H+2, W+2, C) of the bf16 activation path.
+template <int MT, bool BF16CL = false>
 __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __restrict__ dO_pad,
-                                                              const float* __restrict__ a_pad,
+                                                              const void* __restrict__ a_pad_,
                                                               float* __restrict__ slabs, float* __restrict__ bias_slabs,
                                                               int N, int C, int D, int H, int W, int steps) {
   extern __shared__ __align__(16) float red[];  // [(9 + 1)*MT][256]
@@ -329,12 +340,21 @@ __global__ __launch_bounds__(256) void head_bwd_weight_kernel(const float* __res
       const float v = dO_pad[((size_t)n * 16 * MT + m * 16 + j) * volp + off + (size_t)Hp * Wp + Wp + 1];
       a[m] = ok ? v : 0.f;
     }
-    const float* bp = a_pad + ((size_t)n * C + ct * 16 + j) * volp + off + (size_t)kd * Hp * Wp;
     float b[9];
+    if (BF16CL) {
+      const unsigned short* bp = reinterpret_cast<const unsigned short*>(a_pad_) +
+                                 ((size_t)n * volp + off + (size_t)kd * Hp * Wp) * C + ct * 16 + j;
 #pragma unroll
-    for (int kh = 0; kh < 3; ++kh)
+      for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-      for (int kw = 0; kw < 3; ++kw) b[kh * 3 + kw] = bp[kh * Wp + kw];
+        for (int kw = 0; kw < 3; ++kw) b[kh * 3 + kw] = msl::bf2f(bp[(size_t)(kh * Wp + kw) * C]);
+    } else {
+      const float* bp = reinterpret_cast<const float*>(a_pad_) + ((size_t)n * C + ct * 16 + j) * volp + off + (size_t)kd * Hp * Wp;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) b[kh * 3 + kw] = bp[kh * Wp + kw];
+    }
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -565,9 +585,9 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
 
 // ---- bwd-data.  grid (S/64, ceil(C/16 / cts), N): the dO slab of the block is staged once, the weight fragments per
 // 16-channel tile.
-template <int W, int MT>
+template <int W, int MT, bool BF16OUT = false>
 __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __restrict__ dO_pad,
-                                                                const float* __restrict__ Wb, float* __restrict__ g_a,
+                                                                const float* __restrict__ Wb, void* __restrict__ g_a_,
                                                                 int C, int D, int cts) {
   typedef HeadGeo<W> G;
   constexpr int SLAB = G::PD * G::PH * G::PW, CO = 16 * MT, COG = 4 * MT;
@@ -624,7 +644,11 @@ __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __r
     }
     acc += acc2;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) g_a[((size_t)n * C + ct * 16 + 4 * q + r) * S + P] = acc[r];
+    for (int r = 0; r < 4; ++r) {
+      const size_t o = ((size_t)n * C + ct * 16 + 4 * q + r) * S + P;
+      if (BF16OUT) reinterpret_cast<unsigned short*>(g_a_)[o] = msl::f2bf(acc[r]);
+      else reinterpret_cast<float*>(g_a_)[o] = acc[r];
+    }
   }
 }
 
@@ -633,11 +657,15 @@ __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __r
 // against the 9 taps of the plane.  HEAD_BWW_SB blocks form one stage (36 MFMAs per wave and block are 0.5 us, an L2
 // round trip under load ~1.5 us: with one block per stage every stage waited for its loads).  Same slab / bias-slab
 // layout as head_bwd_weight_kernel.
+// BF16CL: the feature map is the bf16 channels-last copy (N, D+2, H+2, W+2, C) of the bf16 activation path; a thread then
+// stages 8 channels of a voxel per 16-byte load.
 constexpr int HEAD_BWW_SB = 4;
-template <int W, int MT>
-__global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restrict__ dO_pad, const float* __restrict__ a_pad,
+template <int W, int MT, bool BF16CL = false>
+__global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restrict__ dO_pad, const void* __restrict__ a_pad_,
                                                            float* __restrict__ slabs, float* __restrict__ bias_slabs, int N,
                                                            int C, int D, int blocks_per_wg) {
+  const float* a_pad = reinterpret_cast<const float*>(a_pad_);
+  const hu16* a_cl = reinterpret_cast<const hu16*>(a_pad_);
   typedef HeadGeo<W> G;
   constexpr int PDK = G::PD - 2, SLABK = PDK * G::PH * G::PW, CO = 16 * MT, DLD = 66, SB = HEAD_BWW_SB;
   constexpr int NS = (16 * SLABK + 255) / 256;
@@ -671,7 +699,19 @@ __global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restri
     gdo[i] = e < CO * 64 ? (int)(co * volp) + ((dd + 1) * Hp + hh + 1) * Hp + ww + 1 : -1;
     ldo[i] = co * DLD + pb;
   }
-  float sv[SB][NS], dv[SB][ND];
+  // channels-last staging roles: element e -> (slab position r, channel half): one 16-byte load, 8 LDS stores
+  constexpr int NSB = (2 * SLABK + 255) / 256;
+  int gcl[NSB], lcl[NSB];
+#pragma unroll
+  for (int i = 0; i < NSB; ++i) {
+    const int e = tid + 256 * i;
+    const int r = e >> 1, hf = e & 1;
+    const int pd = r / (G::PH * G::PW), ph = (r / G::PW) % G::PH, pw = r % G::PW;
+    gcl[i] = e < 2 * SLABK ? (((kd + pd) * Hp + ph) * Hp + pw) * C + ct * 16 + hf * 8 : -1;
+    lcl[i] = hf * 8 * G::CSK + r;
+  }
+  float sv[BF16CL ? 1 : SB][BF16CL ? 1 : NS], dv[SB][ND];
+  hu16x8 cv[BF16CL ? SB : 1][BF16CL ? NSB : 1];
   // loads of the stage that starts at block b0 (blocks past the range are clamped: their products are skipped)
   auto load_stage = [&](int b0) {
 #pragma unroll
@@ -681,7 +721,13 @@ __global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restri
       int d0, h0;
       head_block_origin<W>(b, d0, h0);
       const int org = (d0 * Hp + h0) * Hp;
-      head_ld_f1(sv[u], a_pad + ((size_t)n * C + ct * 16) * volp + org, gsp);
+      if constexpr (BF16CL) {
+        const hu16* ap = a_cl + ((size_t)n * volp + org) * C;
+#pragma unroll
+        for (int i = 0; i < NSB; ++i) cv[u][i] = *reinterpret_cast<const hu16x8*>(ap + (gcl[i] < 0 ? 0 : gcl[i]));
+      } else {
+        head_ld_f1(sv[u], a_pad + ((size_t)n * C + ct * 16) * volp + org, gsp);
+      }
       head_ld_f1(dv[u], dO_pad + (size_t)n * CO * volp + org, gdo);
     }
   };
@@ -694,7 +740,16 @@ __global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restri
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SB; ++u) {
-      head_st_f1(sv[u], lds + u * (FSZ + DSZ), gsp, lsp);
+      if constexpr (BF16CL) {
+#pragma unroll
+        for (int i = 0; i < NSB; ++i)
+          if (gcl[i] >= 0) {
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lds[u * (FSZ + DSZ) + lcl[i] + k * G::CSK] = msl::bf2f(cv[u][i][k]);
+          }
+      } else {
+        head_st_f1(sv[u], lds + u * (FSZ + DSZ), gsp, lsp);
+      }
       head_st_f1(dv[u], lds + u * (FSZ + DSZ) + FSZ, gdo, ldo);
     }
     __syncthreads();
@@ -778,9 +833,6 @@ inline int head_lds_w(int C, int D, int H, int W, int MT = 1) {
 // k-step - 8 consecutive channels of one voxel per lane - is ONE 16-byte load; k-step = (tap, 32-channel group).  The
 // weights are packed per step as [tap][C/32][lane][8] bf16 (co = lane & 15, ci = 32*cg + 8*(lane >> 4) + j; rows >= 12 +
 // 2*ncls are zero).  Outputs are the same fp32 (N, P, 6) / (N, P, ncls) rows as the fp32 kernels write.
-typedef __bf16 hbf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned short hu16;
-typedef hu16 hu16x8 __attribute__((ext_vector_type(8)));
 
 __global__ void head_pack_weights_bf16_kernel(const float* __restrict__ loc_w, const float* __restrict__ cl_w,
                                               hu16* __restrict__ Wp, int C, int co_total) {
@@ -1011,8 +1063,8 @@ int msl_head_grad_pack(const float* dlocs, const float* dscores, float* dO_pad, 
   return MSL_OK;
 }
 
-int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int N, int C, int D, int H, int W,
-                           int ncls, void* stream) {
+static int head_bwd_data_impl(const float* dO_pad, const float* Wb, void* g_a, int N, int C, int D, int H, int W, int ncls,
+                              bool bf16_out, void* stream) {
   if (C % 16 != 0) return MSL_ERR_ARG;
   const int S = D * H * W, MT = head_mt(ncls);
   hipStream_t st = (hipStream_t)stream;
@@ -1022,18 +1074,38 @@ int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int
     const int gy = std::max(1, std::min(ctiles, 256 / blocks));
     const int cts = msl::cdiv(ctiles, gy);
     dim3 grid(S / 64, msl::cdiv(ctiles, cts), N);
-#define MSL_HB(W_, MT_) \
-  hipLaunchKernelGGL((head_bwd_data_lds_kernel<W_, MT_>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, cts)
-    if (lw == 16) MSL_HB(16, 1); else if (lw == 8) MSL_HB(8, 1); else MSL_HB(4, 1);
+#define MSL_HB(W_, B_) \
+  hipLaunchKernelGGL((head_bwd_data_lds_kernel<W_, 1, B_>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, cts)
+    if (bf16_out) {
+      if (lw == 16) MSL_HB(16, true); else if (lw == 8) MSL_HB(8, true); else MSL_HB(4, true);
+    } else {
+      if (lw == 16) MSL_HB(16, false); else if (lw == 8) MSL_HB(8, false); else MSL_HB(4, false);
+    }
 #undef MSL_HB
     MSL_LAUNCH_CHECK();
     return MSL_OK;
   }
   dim3 grid(msl::cdiv(S, 32), msl::cdiv(C, 64), N);
-  if (MT == 1) hipLaunchKernelGGL(head_bwd_data_kernel<1>, grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
-  else hipLaunchKernelGGL(head_bwd_data_kernel<2>, grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+  if (bf16_out) {
+    if (MT == 1) hipLaunchKernelGGL((head_bwd_data_kernel<1, true>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+    else hipLaunchKernelGGL((head_bwd_data_kernel<2, true>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+  } else {
+    if (MT == 1) hipLaunchKernelGGL((head_bwd_data_kernel<1, false>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+    else hipLaunchKernelGGL((head_bwd_data_kernel<2, false>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+  }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
+}
+
+int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int N, int C, int D, int H, int W,
+                           int ncls, void* stream) {
+  return head_bwd_data_impl(dO_pad, Wb, g_a, N, C, D, H, W, ncls, false, stream);
+}
+
+// bf16 activation path: the same with a bf16 gradient tensor g_a (N,C,D,H,W)
+int msl_head_conv_bwd_data_bf16(const float* dO_pad, const float* Wb, void* g_a_bf16, int N, int C, int D, int H, int W,
+                                int ncls, void* stream) {
+  return head_bwd_data_impl(dO_pad, Wb, g_a_bf16, N, C, D, H, W, ncls, true, stream);
 }
 
 // workspace = [nblocks][C/16][27*MT][16][16] weight slabs followed by [nblocks][16*MT] bias slabs
@@ -1051,9 +1123,24 @@ int msl_head_conv_bwd_weight_nslabs(int N, int C, int D, int H, int W, int ncls)
 // dloc_w == NULL (then dcl_w / dloc_b / dcl_b are ignored): leave the partial slabs in `workspace` (deferred reduction:
 // msl_grad_reduce_batch kind 3 for the weights, kind 0 on the bias slabs at float offset nslabs*(C/16)*27*MT*256 with
 // stride 16*MT: rows 0-11 -> dloc_b, rows 12.. -> dcl_b).
+static int head_bww_impl(const float* dO_pad, const void* a_pad, bool bf16_cl, float* dloc_w, float* dcl_w, float* dloc_b,
+                         float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls, void* stream);
+
 int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dloc_w, float* dcl_w,
                              float* dloc_b, float* dcl_b, float* workspace, int N, int C, int D, int H, int W,
                              int ncls, void* stream) {
+  return head_bww_impl(dO_pad, a_pad, false, dloc_w, dcl_w, dloc_b, dcl_b, workspace, N, C, D, H, W, ncls, stream);
+}
+
+// bf16 activation path: the feature map is the bf16 channels-last copy (N,D+2,H+2,W+2,C) of msl_bn_relu_materialize_bf16.
+int msl_head_conv_bwd_weight_bf16(const float* dO_pad, const void* a_cl, float* dloc_w, float* dcl_w, float* dloc_b,
+                                  float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls,
+                                  void* stream) {
+  return head_bww_impl(dO_pad, a_cl, true, dloc_w, dcl_w, dloc_b, dcl_b, workspace, N, C, D, H, W, ncls, stream);
+}
+
+static int head_bww_impl(const float* dO_pad, const void* a_pad, bool bf16_cl, float* dloc_w, float* dcl_w, float* dloc_b,
+                         float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls, void* stream) {
   if (C % 16 != 0) return MSL_ERR_ARG;
   const int MT = head_mt(ncls), co_total = 12 + 2 * ncls;
   HwPlan p = head_bw_plan(N, C, D, H, W, MT);
@@ -1061,18 +1148,26 @@ int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dlo
   dim3 grid(p.nblocks, C / 16, 3);
   float* bias_slabs = workspace + (size_t)p.nblocks * (C / 16) * 27 * MT * 256;
   if (p.lds_w) {
-#define MSL_HW(W_, MT_)                                                                                               \
-  hipLaunchKernelGGL((head_bww_lds_kernel<W_, MT_>), grid, dim3(256), 0, st, dO_pad, a_pad, workspace, bias_slabs, N, \
+#define MSL_HW(W_, B_)                                                                                               \
+  hipLaunchKernelGGL((head_bww_lds_kernel<W_, 1, B_>), grid, dim3(256), 0, st, dO_pad, a_pad, workspace, bias_slabs, N, \
                      C, D, p.bpw)
-    if (p.lds_w == 16) MSL_HW(16, 1); else if (p.lds_w == 8) MSL_HW(8, 1); else MSL_HW(4, 1);
+    if (bf16_cl) {
+      if (p.lds_w == 16) MSL_HW(16, true); else if (p.lds_w == 8) MSL_HW(8, true); else MSL_HW(4, true);
+    } else {
+      if (p.lds_w == 16) MSL_HW(16, false); else if (p.lds_w == 8) MSL_HW(8, false); else MSL_HW(4, false);
+    }
 #undef MSL_HW
   } else {
     const size_t lds = (size_t)10 * MT * 256 * sizeof(float);
-    if (MT == 1) {
-      hipLaunchKernelGGL(head_bwd_weight_kernel<1>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
+#define MSL_HG(M_, B_)                                                                                                  \
+  hipLaunchKernelGGL((head_bwd_weight_kernel<M_, B_>), grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, \
+                     D, H, W, p.steps)
+    if (bf16_cl) {
+      if (MT == 1) MSL_HG(1, true); else MSL_HG(2, true);
     } else {
-      hipLaunchKernelGGL(head_bwd_weight_kernel<2>, grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, D, H, W, p.steps);
+      if (MT == 1) MSL_HG(1, false); else MSL_HG(2, false);
     }
+#undef MSL_HG
   }
   MSL_LAUNCH_CHECK();
   if (!dloc_w) return MSL_OK;

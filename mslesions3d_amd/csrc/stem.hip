@@ -302,7 +302,8 @@ struct StemFusedSrc {
   int OD1, OH1, OW1;  // dims of dL/dz
 };
 
-template <int CIN, int MODE>
+// BF16ACT (MODE 0 / 1 only): dy and yraw are bf16 tensors (bf16 activation path); everything else as in fp32.
+template <int CIN, int MODE, bool BF16ACT = false>
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               float* __restrict__ slabs, int N, int D, int H, int W,
                                                               int OD, int OH, int OW, int sd, int sh, int sw,
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
                                                               const float* __restrict__ w1p, StemFusedSrc fs) {
   constexpr bool APPLY = MODE >= 1;
   constexpr bool FUSED = MODE == 2;
+  static_assert(!(FUSED && BF16ACT), "the fused stem backward is fp32 only");
   constexpr int NT = (CIN * 27 + 31) / 32;
   constexpr int WAVE_LDS = 32 * SB_DY_LD + CIN * 9 * SB_ROW_LD;
   extern __shared__ __align__(16) float lds[];
@@ -554,13 +556,24 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     const bool in = lane < npos;
     {
       const size_t off = (size_t)n * 32 * OS + ((size_t)od * OH + oh) * OW + ow0 + (in ? lane : 0);
-      const float* src = dy + off;
+      if (BF16ACT) {
+        const unsigned short* src = reinterpret_cast<const unsigned short*>(dy) + off;
 #pragma unroll
-      for (int co = 0; co < 32; ++co) dreg[co] = src[(size_t)co * OS];
-      if (APPLY) {
-        const float* ysrc = yraw + off;
+        for (int co = 0; co < 32; ++co) dreg[co] = msl::bf2f(src[(size_t)co * OS]);
+        if (APPLY) {
+          const unsigned short* ysrc = reinterpret_cast<const unsigned short*>(yraw) + off;
 #pragma unroll
-        for (int co = 0; co < 32; ++co) yreg[co] = ysrc[(size_t)co * OS];
+          for (int co = 0; co < 32; ++co) yreg[co] = msl::bf2f(ysrc[(size_t)co * OS]);
+        }
+      } else {
+        const float* src = dy + off;
+#pragma unroll
+        for (int co = 0; co < 32; ++co) dreg[co] = src[(size_t)co * OS];
+        if (APPLY) {
+          const float* ysrc = yraw + off;
+#pragma unroll
+          for (int co = 0; co < 32; ++co) yreg[co] = ysrc[(size_t)co * OS];
+        }
       }
     }
     float xreg[CIN * 9][3];
@@ -736,7 +749,8 @@ int msl_stem_conv_bwd_weight_nslabs(int N, int D, int H, int W, int sd, int sh, 
 // dw (32,Cin,3,3,3) = correlation of dy (N,32,OD,OH,OW) with x (N,Cin,D,H,W).  For all three forms: dw == NULL leaves
 // the partial slabs in `workspace` (deferred reduction, msl_grad_reduce_batch kind 2).
 static int stem_bww_impl(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
-                         int sd, int sh, int sw, const float* yraw, const float* bnv, const float* w1, void* stream);
+                         int sd, int sh, int sw, const float* yraw, const float* bnv, const float* w1, void* stream,
+                         bool bf16act = false);
 
 int msl_stem_conv_bwd_weight(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D,
                              int H, int W, int sd, int sh, int sw, void* stream) {
@@ -767,8 +781,18 @@ int msl_stem_conv_bwd_weight_bnapply(const float* g, const float* yraw, const fl
   return stem_bww_impl(g, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, yraw, bn_vec, nullptr, stream);
 }
 
+// bf16 activation path: g (dL/d relu(bn(y))) and yraw are bf16 tensors; same slabs / reduction as msl_stem_conv_bwd_weight_bnapply
+int msl_stem_conv_bwd_weight_bnapply_bf16(const void* g, const void* yraw, const float* bn_vec, const float* x, float* dw,
+                                          float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
+                                          void* stream) {
+  if (!yraw || !bn_vec) return MSL_ERR_ARG;
+  return stem_bww_impl((const float*)g, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, (const float*)yraw, bn_vec, nullptr,
+                       stream, true);
+}
+
 static int stem_bww_impl(const float* dy, const float* x, float* dw, float* workspace, int N, int Cin, int D, int H, int W,
-                         int sd, int sh, int sw, const float* yraw, const float* bnv, const float* w1, void* stream) {
+                         int sd, int sh, int sw, const float* yraw, const float* bnv, const float* w1, void* stream,
+                         bool bf16act) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || sd < 1 || sd > 2 || sh < 1 || sh > 2 || sw < 1 || sw > 2)
     return MSL_ERR_ARG;
   const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
@@ -790,11 +814,25 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
     hipLaunchKernelGGL((stem_bwd_weight_kernel<CI, AP>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, D,  \
                        H, W, OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters, yraw, bnv, w1, fs);        \
   } while (0)
-#define MSL_STEM_BW(CI)                 \
-  do {                                  \
-    if (w1) MSL_STEM_BW1(CI, 2);        \
-    else if (yraw) MSL_STEM_BW1(CI, 1); \
-    else MSL_STEM_BW1(CI, 0);           \
+#define MSL_STEM_BW1B(CI, AP)                                                                                        \
+  do {                                                                                                               \
+    if (lds > 64 * 1024) {                                                                                           \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bwd_weight_kernel<CI, AP, true>),       \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
+      if (e_ != hipSuccess) return (int)e_;                                                                          \
+    }                                                                                                                \
+    hipLaunchKernelGGL((stem_bwd_weight_kernel<CI, AP, true>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, \
+                       D, H, W, OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters, yraw, bnv, w1, fs);     \
+  } while (0)
+#define MSL_STEM_BW(CI)                                \
+  do {                                                 \
+    if (bf16act) {                                     \
+      if (w1) return MSL_ERR_UNSUPPORTED;              \
+      if (yraw) MSL_STEM_BW1B(CI, 1);                  \
+      else MSL_STEM_BW1B(CI, 0);                       \
+    } else if (w1) MSL_STEM_BW1(CI, 2);                \
+    else if (yraw) MSL_STEM_BW1(CI, 1);                \
+    else MSL_STEM_BW1(CI, 0);                          \
   } while (0)
   switch (Cin) {
     case 1: MSL_STEM_BW(1); break;
@@ -805,6 +843,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
   }
 #undef MSL_STEM_BW
 #undef MSL_STEM_BW1
+#undef MSL_STEM_BW1B
   MSL_LAUNCH_CHECK();
   if (!dw) return MSL_OK;  // deferred: the caller folds the slabs with msl_grad_reduce_batch (kind 2)
   const int K = Cin * 27;

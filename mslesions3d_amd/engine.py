@@ -267,8 +267,8 @@ class Engine:
         return self.arena
 
     def plan_for(self, x, need_grad):
-        if getattr(self.model, "compute_dtype", "f32") == "bf16" and not need_grad:
-            return self._plan_bf16(x)
+        if getattr(self.model, "compute_dtype", "f32") == "bf16":
+            return self._plan_bf16(x, need_grad)
         key = (x.shape[0], tuple(x.shape[2:]), x.device, need_grad)
         p = self.plans.get(key)
         if p is None:
@@ -374,9 +374,8 @@ class Engine:
         L = _lib.load()
         m = self.model
         if getattr(m, "compute_dtype", "f32") == "bf16":
-            if training:
-                raise NotImplementedError("the bf16 activation path covers inference (eval mode) only; train in fp32")
-            return self._forward_bf16(x, want_features=want_features, nan_check=nan_check)
+            return self._forward_bf16(x, training=training, need_grad=need_grad, want_features=want_features,
+                                      nan_check=nan_check)
         x = x.contiguous().float()
         self.ensure_arena(x.device)
         pl = self.plan_for(x, need_grad)
@@ -496,9 +495,10 @@ class Engine:
         return pl.locs, pl.scores
 
     # ------------------------------------------------------------------------------------------------
-    def _plan_bf16(self, x):
-        """Buffers of the bf16 inference pass for this input shape (BASELINE configs[3])."""
-        key = ("bf16", x.shape[0], tuple(x.shape[2:]), x.device)
+    def _plan_bf16(self, x, need_grad=False):
+        """Buffers of the bf16 activation path for this input shape: inference (BASELINE configs[3]) and, with
+        ``need_grad``, the training step (configs[2])."""
+        key = ("bf16", x.shape[0], tuple(x.shape[2:]), x.device, need_grad)
         pl = self.plans.get(key)
         if pl is not None:
             return pl
@@ -508,6 +508,7 @@ class Engine:
         class _P:
             pass
         pl = _P()
+        pl.bf16 = True
         N, dev = x.shape[0], x.device
         pl.N, pl.in_dims = N, tuple(x.shape[2:])
         pl.dims, cur = [], tuple(x.shape[2:])
@@ -516,13 +517,24 @@ class Engine:
             pl.dims.append(cur)
         bf = dict(dtype=torch.bfloat16, device=dev)
         f32 = dict(dtype=torch.float32, device=dev)
+        f64 = dict(dtype=torch.float64, device=dev)
+        ncls = m.n_classes
         pl.y = [torch.empty((N, sp["cout"]) + pl.dims[i], **bf) for i, sp in enumerate(specs)]
         pl.z = [None] + [torch.empty((N, specs[i]["cin"]) + pl.dims[i], **bf) for i in range(1, len(specs))]
         pl.bn_y = [torch.zeros((BN_ROWS, sp["cout"]), **f32) for sp in specs]
         pl.bn_z = [None] + [torch.zeros((BN_ROWS, specs[i]["cin"]), **f32) for i in range(1, len(specs))]
-        pl.part_y = [torch.empty(1, dtype=torch.float64, device=dev) for _ in specs]  # eval mode: no statistics
-        pl.part_z = [None] + [torch.empty(1, dtype=torch.float64, device=dev) for _ in specs[1:]]
-        pl.np_y, pl.np_z = [1] * len(specs), [None] + [1] * (len(specs) - 1)
+        # statistics partials of every BatchNorm (training): counts of the bf16 kernels
+        pl.np_y, pl.np_z = [], [None]
+        for i, sp in enumerate(specs):
+            D, H, W = pl.dims[i]
+            if i == 0:
+                pl.np_y.append(L.msl_stem_conv_fwd_num_partials(N, D, H, W))
+            else:
+                pd, ph, pw = pl.dims[i - 1]
+                pl.np_z.append(L.msl_dwconv_fwd_bf16_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]))
+                pl.np_y.append(L.msl_pwconv_fwd_bf16_num_partials(N, D * H * W))
+        pl.part_y = [torch.empty(2 * sp["cout"] * pl.np_y[i], **f64) for i, sp in enumerate(specs)]
+        pl.part_z = [None] + [torch.empty(2 * specs[i]["cin"] * pl.np_z[i], **f64) for i in range(1, len(specs))]
         pl.feat_ids = list(m.aspect_ratios.keys())
         pl.prior_off, off = {}, 0
         for f in pl.feat_ids:
@@ -533,41 +545,88 @@ class Engine:
         pl.fpad_cl = {f: torch.zeros((N,) + tuple(d + 2 for d in pl.dims[f]) + (specs[f]["cout"],), **bf) for f in pl.feat_ids}
         pl.Wp = {f: torch.empty(L.msl_head_packed_weight_bf16_elems(specs[f]["cout"]), **bf) for f in pl.feat_ids}
         pl.locs = torch.empty((N, pl.P, 6), **f32)
-        pl.scores = torch.empty((N, pl.P, m.n_classes), **f32)
+        pl.scores = torch.empty((N, pl.P, ncls), **f32)
         pl.nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
-        pl.events, pl.generation, pl.saved_input, pl.need_grad, pl.trained_mode = {}, 0, None, False, False
+        pl.events, pl.generation, pl.saved_input, pl.need_grad, pl.trained_mode = {}, 0, None, need_grad, False
+        if need_grad:
+            pl.g_y = [torch.empty_like(t) for t in pl.y]
+            pl.g_z = [None] + [torch.empty_like(t) for t in pl.z[1:]]
+            mt16 = 16 * ((12 + 2 * ncls + 15) // 16)
+            pl.dO = {f: torch.zeros((N, mt16) + tuple(d + 2 for d in pl.dims[f]), **f32) for f in pl.feat_ids}
+            pl.Wf, pl.Wb, pl.head_ws = {}, {}, {}
+            for f in pl.feat_ids:
+                C = specs[f]["cout"]
+                ne = L.msl_head_packed_weight_elems(C, ncls)
+                pl.Wf[f], pl.Wb[f] = torch.empty(ne, **f32), torch.empty(ne, **f32)
+                ws = L.msl_head_bwd_weight_workspace_bytes(N, C, *pl.dims[f], ncls)
+                pl.head_ws[f] = torch.empty(max(ws // 4, 1), **f32)
+            pl.head_nslabs = {f: L.msl_head_conv_bwd_weight_nslabs(N, specs[f]["cout"], *pl.dims[f], ncls) for f in pl.feat_ids}
+            pl.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
+            pl.stem_nslabs = L.msl_stem_conv_bwd_weight_nslabs(N, *pl.in_dims, *specs[0]["stride"])
+            pl.pw_nslabs, pl.pw_slabs, pl.dw_np, pl.dw_part = [0], [None], [0], [None]
+            bnp = 0
+            for i in range(1, len(specs)):
+                D, H, W = pl.dims[i]
+                pd, ph, pw = pl.dims[i - 1]
+                ns = L.msl_pwconv_bwd_weight_bf16_nslabs(N, specs[i]["cin"], specs[i]["cout"], D * H * W)
+                if ns < 1:
+                    raise _lib.HipKernelError(f"msl_pwconv_bwd_weight_bf16_nslabs failed for block {i}")
+                pl.pw_nslabs.append(ns)
+                pl.pw_slabs.append(torch.empty(ns * specs[i]["cin"] * specs[i]["cout"], **f32) if ns > 1 else None)
+                pl.dw_np.append(pl.np_z[i])
+                pl.dw_part.append(torch.empty(specs[i]["cin"] * 27 * pl.np_z[i], **f64))
+                bnp = max(bnp, 2 * specs[i]["cout"] * L.msl_bn_relu_bwd_bf16_num_partials(N, D * H * W),
+                          2 * specs[i]["cin"] * L.msl_bn_relu_bwd_bf16_num_partials(N, D * H * W))
+            d0 = pl.dims[0]
+            bnp = max(bnp, 2 * specs[0]["cout"] * L.msl_bn_relu_bwd_bf16_num_partials(N, d0[0] * d0[1] * d0[2]))
+            pl.partials = torch.empty(bnp, **f64)
+            pl.fused_stem_np = -1
+            pl.grad_tables = {}
         self.plans[key] = pl
         return pl
 
-    def _forward_bf16(self, x, want_features=False, nan_check=True):
-        """Eval-mode forward with bf16 activations in HBM (csrc/bf16.hip + the bf16 head kernel): fp32 input volume,
-        fp32 weights and BatchNorm vectors, bf16 everything in between, fp32 locs / scores out.  One stream."""
+    def _forward_bf16(self, x, training=False, need_grad=False, want_features=False, nan_check=True):
+        """Forward with bf16 activations in HBM (csrc/bf16.hip + the bf16 head kernel): fp32 input volume, fp32 weights and
+        BatchNorm vectors / statistics, bf16 everything in between, fp32 locs / scores out.  One stream (the head
+        convolutions are issued in line)."""
         m, specs, feats = self.model, self.layer_specs, self.model.base.features
         x = x.contiguous().float()
         self.ensure_arena(x.device)
-        pl = self._plan_bf16(x)
+        pl = self._plan_bf16(x, need_grad)
         pl.generation += 1
+        pl.saved_input, pl.trained_mode = x, training
         st = self._stream()
         N = pl.N
-        _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
-        every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], 1, 1.0)]
-        for i in range(1, len(specs)):
-            every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], 1, 1.0), (feats[i].bn2, pl.bn_y[i], pl.part_y[i], 1, 1.0)]
-        self._finalize_all(pl, every, st, eval_mode=True)
-        D, H, W = pl.in_dims
-        self._k("stem_fwd", "msl_stem_conv_fwd_bf16", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), None, N,
-                specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
-        out_feats = {}
         ncls = m.n_classes
+        _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
+        if not training:
+            every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], 1, 1.0)]
+            for i in range(1, len(specs)):
+                every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], 1, 1.0), (feats[i].bn2, pl.bn_y[i], pl.part_y[i], 1, 1.0)]
+            self._finalize_all(pl, every, st, eval_mode=True)
+        if need_grad:  # fp32 fragment copies for the head bwd-data kernel
+            self._pack_head_weights(pl, st)
+        part = (lambda t: ptr(t)) if training else (lambda t: None)
+        D, H, W = pl.in_dims
+        self._k("stem_fwd", "msl_stem_conv_fwd_bf16", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), part(pl.part_y[0]), N,
+                specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        od, oh, ow = pl.dims[0]
+        if training:
+            self._bn_fwd(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], N * od * oh * ow, True, st)
+        out_feats = {}
         for i in range(1, len(specs)):
             sp, blk = specs[i], feats[i]
             pd, ph, pw = pl.dims[i - 1]
             D, H, W = pl.dims[i]
             S = D * H * W
             self._k(f"dw_fwd{i}", "msl_dwconv_fwd_bf16", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
-                    ptr(blk.conv1.weight), ptr(pl.z[i]), None, N, sp["cin"], pd, ph, pw, sp["stride"][0], st)
+                    ptr(blk.conv1.weight), ptr(pl.z[i]), part(pl.part_z[i]), N, sp["cin"], pd, ph, pw, sp["stride"][0], st)
+            if training:
+                self._bn_fwd(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, True, st)
             self._k(f"pw_fwd{i}", "msl_pwconv_fwd_bf16", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
-                    ptr(blk.conv2.weight), ptr(pl.y[i]), None, N, sp["cin"], sp["cout"], S, st)
+                    ptr(blk.conv2.weight), ptr(pl.y[i]), part(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
+            if training:
+                self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
             if i in pl.fpad_cl:
                 plain = None
                 if want_features:
@@ -586,6 +645,80 @@ class Engine:
         if want_features:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores
+
+    def _bn_bwd_bf16(self, g, y, vec, bn_name, N, C, S, pl, st):
+        """In place: g (bf16, = dL/d relu(bn(y))) becomes dL/dy; dgamma / dbeta into the gradient arena."""
+        L = _lib.load()
+        gv = self.arena.grad_views
+        if N * S <= 65536:
+            self._k("bn_bwd_fused:" + bn_name, "msl_bn_relu_bwd_fused_bf16", ptr(g), ptr(y), ptr(vec), ptr(gv[bn_name + ".weight"]),
+                    ptr(gv[bn_name + ".bias"]), ptr(g), N, C, S, st)
+            return
+        NP = L.msl_bn_relu_bwd_bf16_num_partials(N, S)
+        self._k("bn_bwd_reduce:" + bn_name, "msl_bn_relu_bwd_reduce_bf16", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+                ptr(vec[3]), ptr(pl.partials), N, C, S, st)
+        _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(N * S), ptr(gv[bn_name + ".weight"]),
+                  ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
+        self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply_bf16", ptr(g), ptr(y), ptr(vec), ptr(g), N, C, S, st)
+
+    def _backward_bf16(self, pl, dlocs, dscores, on_bucket_ready=None):
+        """Backward of the bf16 training step: activation gradients are bf16 tensors, weight gradients fp32 partial sums
+        folded by the batched reduction; one stream, and a data-parallel reducer gets all its buckets at the end."""
+        m, specs, feats = self.model, self.layer_specs, self.model.base.features
+        gv = self.arena.grad_views
+        st = self._stream()
+        N, ncls = pl.N, m.n_classes
+        dlocs, dscores = dlocs.contiguous(), dscores.contiguous()
+        last = len(specs) - 1
+        for k, f in enumerate(pl.feat_ids):
+            C = specs[f]["cout"]
+            D, H, W = pl.dims[f]
+            self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P,
+                    pl.prior_off[f], ncls, st)
+            self._k(f"head_bwd{f}", "msl_head_conv_bwd_data_bf16", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W,
+                    ncls, st)
+            self._k(f"head_bww{f}", "msl_head_conv_bwd_weight_bf16", ptr(pl.dO[f]), ptr(pl.fpad_cl[f]), None, None, None, None,
+                    ptr(pl.head_ws[f]), N, C, D, H, W, ncls, st)
+        for i in range(last, 0, -1):
+            sp = specs[i]
+            D, H, W = pl.dims[i]
+            S = D * H * W
+            pd, ph, pw = pl.dims[i - 1]
+            s = sp["stride"][0]
+            name = f"base.features.{i}"
+            if i == last and i not in pl.fpad_cl:
+                raise RuntimeError("the last backbone feature must feed a head")
+            self._bn_bwd_bf16(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N, sp["cout"], S, pl, st)
+            out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
+            self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs_bf16", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
+                    ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, st)
+            self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data_bf16", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N,
+                    sp["cin"], sp["cout"], S, st)
+            self._bn_bwd_bf16(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N, sp["cin"], S, pl, st)
+            self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
+                    ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, st)
+            accumulate = 1 if (i - 1) in pl.fpad_cl else 0  # the heads already wrote their share
+            self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bf16", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
+                    sp["cin"], pd, ph, pw, s, accumulate, st)
+        # stem: BatchNorm-backward sums, then the weight gradient with the BatchNorm backward applied on load
+        od, oh, ow = pl.dims[0]
+        S0 = od * oh * ow
+        D, H, W = pl.in_dims
+        L = _lib.load()
+        vec = pl.bn_y[0]
+        NP = L.msl_bn_relu_bwd_bf16_num_partials(N, S0)
+        self._k("bn_bwd_reduce:stem", "msl_bn_relu_bwd_reduce_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec[0]), ptr(vec[1]),
+                ptr(vec[2]), ptr(vec[3]), ptr(pl.partials), N, specs[0]["cout"], S0, st)
+        _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(N * S0), ptr(gv["base.features.0.1.weight"]),
+                  ptr(gv["base.features.0.1.bias"]), ptr(vec[4]), ptr(vec[5]), specs[0]["cout"], st)
+        self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec), ptr(pl.saved_input),
+                None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        self._grad_reduce(pl, "all", None, st)
+        if on_bucket_ready is not None:
+            for stage in ["heads"] + list(range(last, -1, -1)):
+                wanted = getattr(on_bucket_ready, "stages", None)
+                if wanted is None or stage in wanted:
+                    self._hook(on_bucket_ready, stage)
 
     def _finalize_all(self, pl, bn_layers, st, eval_mode=False):
         """One launch for the running statistics and backward vectors of the listed BatchNorms (table built once per
@@ -709,6 +842,8 @@ class Engine:
         ``stages`` attribute only those stages are reported (and the side streams are joined first)."""
         if not pl.need_grad or not pl.trained_mode:
             raise RuntimeError("backward needs a train-mode forward made with gradients enabled")
+        if getattr(pl, "bf16", False):
+            return self._backward_bf16(pl, dlocs, dscores, on_bucket_ready)
         m = self.model
         gv = self.arena.grad_views
         st = self._stream()

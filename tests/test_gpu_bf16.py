@@ -118,6 +118,194 @@ def test_materialize_and_head_fwd_bf16(N, C, dims):
     assert bool((locs[:, :off] == 7).all()) and bool((locs[:, off + 2 * S:] == 7).all())
 
 
+# ------------------------------------------------------------------------------------ backward kernels (configs[2])
+def b16(t):
+    return K(t.detach().to(torch.bfloat16))  # kept alive until the end of the test (see K)
+
+
+@pytest.mark.parametrize("N,Cin,Cout,S", [(2, 32, 64, 1024), (1, 64, 128, 64), (4, 512, 512, 64), (2, 128, 256, 512),
+                                          (3, 64, 128, 4096), (1, 32, 64, 32768), (2, 128, 128, 4096),
+                                          # ragged position counts: the plain one-slab weight-gradient kernel
+                                          (2, 512, 512, 8), (1, 256, 512, 27), (2, 32, 64, 100)])
+def test_pw_bwd_bf16(N, Cin, Cout, S):
+    """Pointwise bwd-data (W^T . dY on the bf16 MFMA) and weight gradient (positions as the MFMA K axis, fp32 slabs +
+    batched reduction) against fp64 products of the same bf16-rounded operands."""
+    from tests.test_gpu_kernels import grad_reduce
+    L = _lib.load()
+    z = bfr(rnd(N, Cin, S, seed=10))
+    w = rnd(Cout, Cin, seed=11) / Cin ** 0.5
+    sc, sh = rnd(Cin, seed=12).abs() + 0.5, rnd(Cin, seed=13, scale=0.3)
+    dy = bfr(rnd(N, Cout, S, seed=14))
+    g = torch.full((N, Cin, S), float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("msl_pwconv_bwd_data_bf16", ptr(b16(dy)), ptr(K(w)), ptr(g), N, Cin, Cout, S, st())
+    ref = torch.einsum("oc,nos->ncs", bfr(w).double(), dy.double()).float()
+    close(g.float(), ref, 2 * BF_EPS, 1e-5, "pw bwd data bf16")
+    a = bfr(torch.relu(z * sc.view(1, -1, 1) + sh.view(1, -1, 1)))
+    refw = torch.einsum("nos,ncs->oc", dy.double(), a.double()).float()
+    ns = L.msl_pwconv_bwd_weight_bf16_nslabs(N, Cin, Cout, S)
+    assert ns >= 1
+    slabs = torch.full((ns, Cout, Cin), float("nan"), device=DEV)
+    _lib.call("msl_pwconv_bwd_weight_slabs_bf16", ptr(b16(dy)), ptr(b16(z)), ptr(K(sc)), ptr(K(sh)), ptr(slabs), N, Cin, Cout, S,
+              st())
+    if ns == 1:
+        out = slabs[0]
+    else:
+        out = torch.full((Cout, Cin), float("nan"), device=DEV)
+        grad_reduce([(0, slabs, out, None, ns, Cout * Cin, Cout * Cin, 0, 0, 0)])
+    # an activation next to a bf16 rounding boundary may land one ulp apart (fma here, multiply + add in torch)
+    close(out, refw, 1e-3, 4e-3 * float(refw.abs().max()), "pw bwd weight bf16")
+    slabs2 = torch.full((ns, Cout, Cin), float("nan"), device=DEV)  # without the input affine: exact operands
+    _lib.call("msl_pwconv_bwd_weight_slabs_bf16", ptr(b16(dy)), ptr(b16(z)), None, None, ptr(slabs2), N, Cin, Cout, S, st())
+    refw2 = torch.einsum("nos,ncs->oc", dy.double(), z.double()).float()
+    close(slabs2.double().sum(0).float(), refw2, 1e-4, max(1e-4, 5e-6 * float(refw2.abs().max())), "pw bwd weight bf16, no affine")
+
+
+@pytest.mark.parametrize("N,C,dims,stride", [(1, 4, (10, 40, 40), 2), (2, 8, (9, 24, 24), 1), (1, 3, (7, 6, 6), 1),
+                                             (2, 16, (12, 12, 12), 2), (1, 2, (5, 7, 9), 2), (2, 32, (16, 16, 16), 2),
+                                             (2, 64, (8, 8, 8), 1), (1, 2, (4, 128, 128), 2)])
+def test_dw_bwd_bf16(N, C, dims, stride):
+    L = _lib.load()
+    x = bfr(rnd(N, C, *dims, seed=4))
+    w = rnd(C, 1, 3, 3, 3, seed=5, scale=0.4).requires_grad_(True)
+    sc, sh = rnd(C, seed=6).abs() + 0.5, rnd(C, seed=7, scale=0.3)
+    a = torch.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1)).requires_grad_(True)
+    out = F.conv3d(a, w, stride=stride, padding=1, groups=C)
+    dy = bfr(rnd(*out.shape, seed=8))
+    out.backward(dy)
+    g = torch.full(x.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("msl_dwconv_bwd_data_bf16", ptr(b16(dy)), ptr(K(w.detach())), ptr(g), N, C, *dims, stride, 0, st())
+    close(g.float(), a.grad, 2 * BF_EPS, 1e-5, "dw bwd data bf16")
+    base = bfr(rnd(*x.shape, seed=9))
+    g2 = b16(base)
+    _lib.call("msl_dwconv_bwd_data_bf16", ptr(b16(dy)), ptr(K(w.detach())), ptr(g2), N, C, *dims, stride, 1, st())
+    close(g2.float(), base + a.grad, 2 * BF_EPS, 1e-5, "dw bwd data bf16 (accumulate)")
+    NP = L.msl_dwconv_fwd_bf16_num_partials(N, C, *dims, stride)
+    part = torch.full((C * 27, NP), float("nan"), dtype=torch.float64, device=DEV)
+    _lib.call("msl_dwconv_bwd_weight_bf16", ptr(b16(dy)), ptr(b16(x)), ptr(K(sc)), ptr(K(sh)), ptr(part), N, C, *dims, stride, st())
+    close(part.sum(1).float().view(C, 1, 3, 3, 3), w.grad, 1e-4, 1e-4, "dw bwd weight bf16")
+
+
+@pytest.mark.parametrize("N,C,S", [(3, 8, 192), (2, 64, 4096), (4, 32, 32768), (1, 16, 100), (2, 512, 64)])
+def test_bn_relu_bwd_bf16(N, C, S):
+    L = _lib.load()
+    y = bfr(rnd(N, C, S, seed=20) * 2 + 1).requires_grad_(True)
+    gamma, beta = (rnd(C, seed=21).abs() + 0.5).requires_grad_(True), rnd(C, seed=22, scale=0.2).requires_grad_(True)
+    a = torch.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    g = bfr(rnd(*a.shape, seed=25))
+    a.backward(g)
+    yd = y.detach().double()
+    part = torch.stack([yd.sum((0, 2)), (yd ** 2).sum((0, 2))]).view(2, C, 1).contiguous().to(DEV)
+    vec = torch.zeros((8, C), device=DEV)
+    _lib.call("msl_bn_finalize", ptr(part), 1, float(N * S), ptr(K(gamma.detach())), ptr(K(beta.detach())), None, None, None, 0.1,
+              1e-5, ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C, st())
+    NP = L.msl_bn_relu_bwd_bf16_num_partials(N, S)
+    bp = torch.full((2 * C * NP,), float("nan"), dtype=torch.float64, device=DEV)
+    gd, yd16 = b16(g), b16(y.detach())
+    _lib.call("msl_bn_relu_bwd_reduce_bf16", ptr(gd), ptr(yd16), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(bp), N, C,
+              S, st())
+    dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.call("msl_bn_bwd_finalize", ptr(bp), NP, float(N * S), ptr(dgam), ptr(dbet), ptr(vec[4]), ptr(vec[5]), C, st())
+    out = torch.full(y.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("msl_bn_relu_bwd_apply_bf16", ptr(gd), ptr(yd16), ptr(vec), ptr(out), N, C, S, st())
+    close(dgam, gamma.grad, 1e-4, 1e-4, "dgamma")
+    close(dbet, beta.grad, 1e-4, 1e-4, "dbeta")
+    atol = 2 * BF_EPS * float(y.grad.abs().max())  # the result is a difference of terms rounded once at the end
+    close(out.float(), y.grad, 2 * BF_EPS, atol, "bn bwd dy bf16")
+    if N * S <= 65536:
+        g2 = gd.clone()
+        dg2, db2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        _lib.call("msl_bn_relu_bwd_fused_bf16", ptr(g2), ptr(yd16), ptr(vec), ptr(dg2), ptr(db2), ptr(g2), N, C, S, st())
+        close(dg2, gamma.grad, 1e-4, 1e-4, "fused dgamma")
+        close(db2, beta.grad, 1e-4, 1e-4, "fused dbeta")
+        close(g2.float(), y.grad, 2 * BF_EPS, atol, "fused bn bwd dy bf16 (in place)")
+
+
+@pytest.mark.parametrize("N,C,dims", [(2, 128, (16, 16, 16)), (4, 256, (8, 8, 8)), (4, 512, (4, 4, 4)), (1, 32, (8, 4, 4)),
+                                      (3, 48, (8, 8, 8)), (2, 32, (3, 5, 6)), (2, 64, (2, 2, 2))])
+def test_heads_bwd_bf16(N, C, dims):
+    """Head bwd-data writing a bf16 gradient map, and the head weight gradient reading the bf16 channels-last feature
+    copy, against autograd on the same (bf16-representable) activation."""
+    from tests.test_gpu_kernels import grad_reduce
+    L = _lib.load()
+    ncls = 2
+    a = bfr(torch.relu(rnd(N, C, *dims, seed=30))).requires_grad_(True)
+    lw = (rnd(12, C, 3, 3, 3, seed=31) / (27 * C) ** 0.5).requires_grad_(True)
+    cw = (rnd(2 * ncls, C, 3, 3, 3, seed=32) / (27 * C) ** 0.5).requires_grad_(True)
+    lb, cb = rnd(12, seed=33, scale=0.1).requires_grad_(True), rnd(2 * ncls, seed=34, scale=0.1).requires_grad_(True)
+    S = dims[0] * dims[1] * dims[2]
+    rl = F.conv3d(a, lw, lb, padding=1).permute(0, 2, 3, 4, 1).reshape(N, -1, 6)
+    rc = F.conv3d(a, cw, cb, padding=1).permute(0, 2, 3, 4, 1).reshape(N, -1, ncls)
+    dl, dc = rnd(*rl.shape, seed=35), rnd(*rc.shape, seed=36)
+    (rl * dl).sum().backward(retain_graph=True)
+    (rc * dc).sum().backward()
+    off, Ptot = 10, 2 * S + 14
+    dlf = torch.zeros((N, Ptot, 6), device=DEV)
+    dcf = torch.zeros((N, Ptot, ncls), device=DEV)
+    dlf[:, off:off + 2 * S] = dl.to(DEV)
+    dcf[:, off:off + 2 * S] = dc.to(DEV)
+    dO = torch.zeros((N, 16) + tuple(d + 2 for d in dims), device=DEV)
+    _lib.call("msl_head_grad_pack", ptr(dlf), ptr(dcf), ptr(dO), N, *dims, Ptot, off, ncls, st())
+    ne = L.msl_head_packed_weight_elems(C, ncls)
+    Wf, Wb = torch.empty(ne, device=DEV), torch.empty(ne, device=DEV)
+    _lib.call("msl_head_pack_weights", ptr(K(lw.detach())), ptr(K(cw.detach())), ptr(Wf), ptr(Wb), C, ncls, st())
+    ga = torch.full(a.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("msl_head_conv_bwd_data_bf16", ptr(dO), ptr(Wb), ptr(ga), N, C, *dims, ncls, st())
+    close(ga.float(), a.grad, 2 * BF_EPS, 1e-5, "head bwd data -> bf16")
+    pad = torch.zeros((N,) + tuple(d + 2 for d in dims) + (C,), dtype=torch.bfloat16, device=DEV)
+    pad[:, 1:-1, 1:-1, 1:-1, :] = a.detach().permute(0, 2, 3, 4, 1).to(DEV).to(torch.bfloat16)
+    ws = torch.empty(L.msl_head_bwd_weight_workspace_bytes(N, C, *dims, ncls) // 4, device=DEV)
+    glw, gcw = torch.full(lw.shape, float("nan"), device=DEV), torch.full(cw.shape, float("nan"), device=DEV)
+    glb, gcb = torch.empty(12, device=DEV), torch.empty(2 * ncls, device=DEV)
+    _lib.call("msl_head_conv_bwd_weight_bf16", ptr(dO), ptr(pad), ptr(glw), ptr(gcw), ptr(glb), ptr(gcb), ptr(ws), N, C, *dims,
+              ncls, st())
+    close(glw, lw.grad, 1e-4, 1e-4, "head dW loc (bf16 feature map)")
+    close(gcw, cw.grad, 1e-4, 1e-4, "head dW cls (bf16 feature map)")
+    close(glb, lb.grad, 1e-4, 1e-4, "head db loc")
+    close(gcb, cb.grad, 1e-4, 1e-4, "head db cls")
+    # deferred form (what the training step uses): slabs + the batched reduction
+    _lib.call("msl_head_conv_bwd_weight_bf16", ptr(dO), ptr(pad), None, None, None, None, ptr(ws), N, C, *dims, ncls, st())
+    ns = L.msl_head_conv_bwd_weight_nslabs(N, C, *dims, ncls)
+    slab = (C // 16) * 27 * 256
+    o1, o2 = torch.full(lw.shape, float("nan"), device=DEV), torch.full(cw.shape, float("nan"), device=DEV)
+    grad_reduce([(3, ws, o1, o2, ns, slab, slab, C, 1, 12 + 2 * ncls)])
+    close(o1, lw.grad, 1e-4, 1e-4, "head dW loc, deferred")
+    close(o2, cw.grad, 1e-4, 1e-4, "head dW cls, deferred")
+
+
+@pytest.mark.parametrize("cin,dims", [(1, (12, 16, 24)), (2, (16, 16, 16)), (1, (32, 32, 32))])
+def test_stem_bwd_weight_bnapply_bf16(cin, dims):
+    """Stem weight gradient from the bf16 gradient / raw output pair with the BatchNorm backward applied on load."""
+    L = _lib.load()
+    N = 2
+    x = rnd(N, cin, *dims, seed=1)
+    w0 = rnd(32, cin, 3, 3, 3, seed=2, scale=0.3)
+    gamma, beta = rnd(32, seed=3).abs() + 0.5, rnd(32, seed=4, scale=0.2)
+    y0 = bfr(F.conv3d(x, w0, stride=2, padding=1)).requires_grad_(True)  # what the bf16 forward stored
+    a0 = torch.relu(F.batch_norm(y0, None, None, gamma, beta, True, 0.1, 1e-5))
+    g = bfr(rnd(*a0.shape, seed=6))
+    a0.backward(g)
+    refdw = torch.nn.grad.conv3d_weight(x, w0.shape, y0.grad, stride=2, padding=1)
+    od, oh, ow = y0.shape[2:]
+    S0 = od * oh * ow
+    yd = y0.detach().double()
+    part = torch.stack([yd.sum((0, 2, 3, 4)), (yd ** 2).sum((0, 2, 3, 4))]).view(2, 32, 1).contiguous().to(DEV)
+    vec = torch.zeros((8, 32), device=DEV)
+    _lib.call("msl_bn_finalize", ptr(part), 1, float(N * S0), ptr(K(gamma)), ptr(K(beta)), None, None, None, 0.1, 1e-5,
+              ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, st())
+    NP = L.msl_bn_relu_bwd_bf16_num_partials(N, S0)
+    bp = torch.zeros(2 * 32 * NP, dtype=torch.float64, device=DEV)
+    gd, yd16 = b16(g), b16(y0.detach())
+    _lib.call("msl_bn_relu_bwd_reduce_bf16", ptr(gd), ptr(yd16), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), ptr(bp), N, 32,
+              S0, st())
+    dgam, dbet = torch.empty(32, device=DEV), torch.empty(32, device=DEV)
+    _lib.call("msl_bn_bwd_finalize", ptr(bp), NP, float(N * S0), ptr(dgam), ptr(dbet), ptr(vec[4]), ptr(vec[5]), 32, st())
+    dw = torch.full((32, cin, 3, 3, 3), float("nan"), device=DEV)
+    ws = torch.empty(L.msl_stem_conv_bwd_weight_workspace_bytes(cin) // 4, device=DEV)
+    _lib.call("msl_stem_conv_bwd_weight_bnapply_bf16", ptr(gd), ptr(yd16), ptr(vec), ptr(K(x)), ptr(dw), ptr(ws), N, cin, *dims, 2,
+              2, 2, st())
+    close(dw, refdw, 2e-4, 1e-4 * max(1.0, float(refdw.abs().max())), "stem dW from bf16 g / y with fused BN apply")
+
+
 def _models(size, seed=1234):
     from mslesions3d_amd.ssd3d import LSSD3D
     from oracle.network import OracleSSD3D
@@ -168,7 +356,7 @@ def test_bf16_inference_against_the_fp32_oracle(size, n):
         assert hit >= 0.9 * len(ob[i])
 
 
-def test_bf16_predict_step_replays_and_training_refuses():
+def test_bf16_predict_step_replays():
     m, _ = _models((64, 64, 64))
     m.compute_dtype = "bf16"
     m.min_score, m.max_overlap, m.top_k = 0.3, 0.3, 20
@@ -179,6 +367,114 @@ def test_bf16_predict_step_replays_and_training_refuses():
         for u, v in zip(a, b):
             assert torch.equal(u, v)
     assert len(m._pred_programs) == 1
+
+
+def _grad_rows(grads, ref_grads):
+    """Per parameter: (relative L2 error, cosine, name) of ``grads`` against ``ref_grads``; worst first."""
+    rows = []
+    for k, r in ref_grads.items():
+        if r is None:
+            continue
+        g, r = grads[k].detach().cpu().double().reshape(-1), r.detach().cpu().double().reshape(-1)
+        rows.append((float((g - r).norm() / (r.norm() + 1e-30)), float((g @ r) / (g.norm() * r.norm() + 1e-30)), k))
+    rows.sort(reverse=True)
+    return rows
+
+
+def _median(rows):
+    return sorted(r[0] for r in rows)[len(rows) // 2]
+
+
+@pytest.mark.parametrize("size,n", [((64, 64, 64), 2), ((128, 128, 128), 4)])
+def test_bf16_training_step_against_the_emulation_and_the_fp32_oracle(size, n):
+    """BASELINE configs[2] (128^3, batch 4, bf16 training) - and 64^3 x 2 - through the autograd API.
+
+    (1) against tests/bf16_emul.py, the CPU restatement of the path's storage semantics (fp32 math on values rounded to
+        bf16 exactly where the kernels store bf16): only the summation order - and the bf16 roundings it tips - differ,
+        but this train-mode network amplifies perturbations by ~1e4 into the gradients (fp32: 1e-7 -> 2e-3, see
+        test_full_gradients_against_oracle), so even that is no tight comparison at model level (the tight ones are the
+        kernel tests above).  Bounds: outputs within 2e-2 of the tensor's max; the gradients must be markedly closer to
+        the emulation than to the fp32 oracle (median relative L2 at most 0.6 of it), i.e. the emulation explains the
+        deviation.
+    (2) REPORTED, loosely bounded: against the fp32 oracle.  The network's backward is checked as a vector-Jacobian
+        product (both sides get the oracle's dL/d(locs, scores): the L1 box loss has a sign() gradient, one regression
+        crossing its target flips a whole +-1/n_pos entry).  With these random weights the train-mode network amplifies
+        storage noise strongly; the yardstick is stock ``torch.autocast(bfloat16)`` of the same oracle, which the path
+        must not exceed by more than a quarter (median over the parameter tensors)."""
+    import copy
+    from oracle import multibox as OMB
+    from tests.bf16_emul import emulated_step
+    m, om = _models(size)
+    x = detinit.make_volume_batch(5, n, 1, size)
+    boxes, labels = detinit.make_gt(8, n, size)
+    om.train()
+    stats0 = copy.deepcopy(om.state_dict())
+    ol, osc = om(x)
+    oc, olc = OMB.multibox_loss(ol, osc, boxes, labels, om.priors_cxcycz, [0.1, 0.2])
+    dl, ds = torch.autograd.grad(oc + olc, (ol, osc), retain_graph=True)
+    torch.autograd.backward((ol, osc), (dl, ds))
+    og = dict((k, p.grad) for k, p in om.named_parameters())
+    # stock mixed precision of the same model, as the yardstick
+    oa = copy.deepcopy(om)
+    oa.load_state_dict(stats0)
+    oa.zero_grad()
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        al, asc = oa(x)
+    torch.autograd.backward((al.float(), asc.float()), (dl, ds))
+    auto = _grad_rows(dict((k, p.grad) for k, p in oa.named_parameters() if p.grad is not None), og)
+    el, es, eg = emulated_step(om, x, dl, ds)
+    emul = _grad_rows(eg, og)
+
     m.train()
-    with pytest.raises(NotImplementedError, match="bf16"):
-        m(detinit.make_volume_batch(5, 2, 1, (64, 64, 64)).to(DEV))
+    m.compute_dtype = "bf16"
+    l, s = m(x.to(DEV))
+    c, lc = m.loss_fn(l, s, [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels])
+    torch.autograd.backward((l, s), (dl.to(DEV), ds.to(DEV)))
+    hg = dict((k, p.grad) for k, p in m.named_parameters() if p.grad is not None)
+    tag = f"bf16 train {size[0]}^3 x{n}"
+    # (1) against the emulation
+    e_l = float((l.detach().cpu() - el).abs().max() / el.abs().max())
+    e_s = float((s.detach().cpu() - es).abs().max() / es.abs().max())
+    tight = _grad_rows(hg, {k: v for k, v in eg.items() if k in hg})
+    print(f"[{tag}] vs the bf16-storage emulation: locs {e_l:.2e}, scores {e_s:.2e}, gradients worst {tight[0]}, median {_median(tight):.2e}")
+    assert e_l <= 2e-2 and e_s <= 2e-2
+    # (2) against the fp32 oracle
+    rows = _grad_rows(hg, og)
+    assert _median(tight) <= 0.6 * _median(rows) and tight[0][0] <= 0.35, (tight[:3], _median(tight), _median(rows))
+    print(f"[{tag}] conf {c.item():.6f} (fp32 oracle {oc.item():.6f}), loc {lc.item():.6f} ({olc.item():.6f}); "
+          f"locs {float((l.detach().cpu() - ol.detach()).abs().max() / ol.detach().abs().max()):.2e} of max, scores {float((s.detach().cpu() - osc.detach()).abs().max() / osc.detach().abs().max()):.2e}")
+    print(f"[{tag}] gradient relative L2 error vs the fp32 oracle, worst / median over the parameter tensors: "
+          f"HIP bf16 {rows[0][0]:.3f} / {_median(rows):.3f}, emulation {emul[0][0]:.3f} / {_median(emul):.3f}, "
+          f"torch.autocast(bfloat16) {auto[0][0]:.3f} / {_median(auto):.3f}")
+    assert abs(c.item() - oc.item()) <= 2e-2 * abs(oc.item()) and abs(lc.item() - olc.item()) <= 2e-2 * abs(olc.item())
+    assert _median(rows) <= 1.25 * _median(auto) + 0.02 and rows[0][0] <= 1.25 * auto[0][0] + 0.05
+    # running statistics follow the same batch statistics
+    for (k, b), (_, ob) in zip(m.named_buffers(), om.named_buffers()):
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            assert float((b.cpu() - ob).abs().max()) <= 2e-2 * float(ob.abs().max()) + 1e-4, k
+
+
+def test_bf16_fused_trainer_follows_the_fp32_trajectory():
+    """Five optimisation steps of FusedTrainer at configs[2] (128^3 x 4): bf16 losses within 3 % of the fp32 product path
+    (itself pinned to the reference goldens), steps 2.. replay the recorded launch program and equal eager execution."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (128, 128, 128), 4
+    runs = {}
+    for tag, dtype, programs in (("f32", "f32", True), ("bf16", "bf16", True), ("bf16-eager", "bf16", False)):
+        m, _ = _models(size)
+        m.train()
+        m.compute_dtype = dtype
+        tr = FusedTrainer(m)
+        tr.use_programs = programs
+        losses = []
+        for step in range(5):
+            xs = detinit.make_volume_batch(50 + step % 2, n, 1, size).to(DEV)
+            bs, ls = detinit.make_gt(60 + step % 2, n, size)
+            out = tr.step(xs, bs, ls)
+            losses.append([out["conf"], out["loc"]])
+        runs[tag] = (np.array(losses), [p.detach().clone() for p in m.parameters()])
+    print("[bf16 trainer] fp32 losses", runs["f32"][0].tolist(), "bf16 losses", runs["bf16"][0].tolist())
+    np.testing.assert_allclose(runs["bf16"][0], runs["f32"][0], rtol=3e-2)
+    assert np.array_equal(runs["bf16"][0], runs["bf16-eager"][0])
+    for a, b in zip(runs["bf16"][1], runs["bf16-eager"][1]):
+        assert torch.equal(a, b)
