@@ -178,6 +178,18 @@ int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dlo
 int msl_stem_conv_fwd_bf16(const float* x, const float* w, void* y_bf16, double* partials, int N, int Cin, int D,
                            int H, int W, int sd, int sh, int sw, void* stream);
 int msl_dwconv_fwd_bf16_num_partials(int N, int C, int D, int H, int W, int stride);
+/* the register-marching wave kernels of the fp32 path on bf16 storage (square power-of-two planes; MSL_ERR_UNSUPPORTED
+ * otherwise - msl_dwconv_*_bf16 try these first and fall back to the LDS-tiled any-shape kernels) */
+int msl_dwconv_wave_num_partials(int N, int C, int D, int H, int W, int stride);
+int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
+                             double* partials, int N, int C, int D, int H, int W, int stride, int flip, int accumulate,
+                             void* stream);
+/* stride-2 bwd-data on bf16 gradients (one thread per 2x2x4 input patch; W % 4 == 0); y_prev != NULL: also the
+ * BatchNorm-backward partials [2][C][NP] of the layer written, NP = msl_dwconv_bwd_data_bnreduce_num_partials */
+int msl_dwconv_bwd_data_s2_patch_bf16(const void* dy, const float* w, void* g_in, const void* y_prev, const float* bn_vec,
+                                      double* partials, int N, int C, int D, int H, int W, int accumulate, void* stream);
+int msl_dwconv_bwd_weight_wave_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift,
+                                    double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
 int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                         double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
 int msl_pwconv_fwd_bf16_num_partials(int N, int S);
@@ -187,6 +199,9 @@ int msl_pwconv_fwd_bf16(const void* z, const float* in_scale, const float* in_sh
 /* relu(bn(y)) of a head feature map -> bf16 CHANNELS-LAST zero-haloed copy (N,D+2,H+2,W+2,C), halo zeroed by the caller */
 int msl_bn_relu_materialize_bf16(const void* y, const float* scale, const float* shift, float* plain, void* pad_cl, int N,
                                  int C, int D, int H, int W, void* stream);
+/* ... fp32 zero-haloed NCDHW copy (N,C,D+2,H+2,W+2) instead: the bf16 TRAINING step runs its heads on the fp32 kernels */
+int msl_bn_relu_materialize_bf16_pad32(const void* y, const float* scale, const float* shift, float* pad, int N, int C, int D,
+                                       int H, int W, void* stream);
 size_t msl_head_packed_weight_bf16_elems(int C);
 int msl_head_pack_weights_bf16(const float* loc_w, const float* cl_w, void* Wp, int C, int ncls, void* stream);
 /* both head convolutions of a scale on v_mfma_f32_16x16x32_bf16, fp32 rows out */

@@ -74,10 +74,15 @@ _SIGNATURES = {
     "msl_head_conv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_stem_conv_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_bf16_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
+    "msl_dwconv_wave_num_partials": (_I, [_I] * 6),
+    "msl_dwconv_fwd_wave_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_data_s2_patch_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_bwd_weight_wave_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_pwconv_fwd_bf16_num_partials": (_I, [_I, _I]),
     "msl_pwconv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_bn_relu_materialize_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msl_bn_relu_materialize_bf16_pad32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msl_head_packed_weight_bf16_elems": (_Z, [_I]),
     "msl_head_pack_weights_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
     "msl_head_conv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -9,6 +9,17 @@
 #include "common.hpp"
 #include <algorithm>
 
+// dwconv.hip: the register-marching wave kernels on bf16 storage (square power-of-two planes)
+extern "C" int msl_dwconv_wave_num_partials(int N, int C, int D, int H, int W, int stride);
+extern "C" int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
+                                        double* partials, int N, int C, int D, int H, int W, int stride, int flip,
+                                        int accumulate, void* stream);
+extern "C" int msl_dwconv_bwd_data_s2_patch_bf16(const void* dy, const float* w, void* g_in, const void* y_prev, const float* bn_vec,
+                                                 double* partials, int N, int C, int D, int H, int W, int accumulate,
+                                                 void* stream);
+extern "C" int msl_dwconv_bwd_weight_wave_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift,
+                                               double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -226,6 +237,20 @@ __global__ __launch_bounds__(256) void materialize_bf16_kernel(const u16* __rest
   }
   const size_t pos = (((size_t)n * (D + 2) + d + 1) * (H + 2) + hh + 1) * (W + 2) + w + 1;
   *reinterpret_cast<u16x8*>(pad_cl + pos * C + c8) = o;
+}
+
+// The training step runs its head convolutions on the fp32 kernels (heads.hip: LDS-staged, faster at these sizes than the
+// bf16 head kernel, and the head operands then carry no second rounding): relu(bn(y)) -> fp32 zero-haloed NCDHW copy
+// (N, C, D+2, H+2, W+2), halo zeroed once at allocation.
+__global__ __launch_bounds__(256) void materialize_bf16_pad32_kernel(const u16* __restrict__ y, const float* __restrict__ scale,
+                                                                     const float* __restrict__ shift, float* __restrict__ pad,
+                                                                     int C, int D, int H, int W) {
+  const int S = D * H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, n = blockIdx.z;
+  if (p >= S) return;
+  const int w = p % W, hh = (p / W) % H, d = p / (W * H);
+  const float v = msl::act(msl::bf2f(y[((size_t)n * C + c) * S + p]), scale[c], shift[c]);
+  pad[(((size_t)(n * C + c) * (D + 2) + d + 1) * (H + 2) + hh + 1) * (W + 2) + w + 1] = v;
 }
 
 // ---- pointwise weight gradient -------------------------------------------------------------------------------------
@@ -542,11 +567,81 @@ __global__ __launch_bounds__(256) void bn_relu_bwd_fused_bf16_kernel(const u16* 
   }
 }
 
+// Register-resident form for N*S <= NT*IPT*8 elements per channel (S % 8 == 0): the channel's g and y are read ONCE (16-byte
+// loads, all of a thread's loads in flight together), kept in registers across the block-wide reduction, and dL/dy is
+// written from them (bn.hip: bn_relu_bwd_fused_reg_kernel, here with 8 bf16 per load).
+template <int NT, int IPT>
+__global__ __launch_bounds__(NT) void bn_relu_bwd_fused_reg_bf16_kernel(const u16* __restrict__ g, const u16* __restrict__ y,
+                                                                        const float* __restrict__ vec, float* __restrict__ dgamma,
+                                                                        float* __restrict__ dbeta, u16* __restrict__ dy, int N,
+                                                                        int C, int S, double count) {
+  __shared__ double scratch[16];
+  __shared__ float coef[2];
+  const int c = blockIdx.x;
+  const float sc = vec[c], sh = vec[C + c], mu = vec[2 * C + c], is = vec[3 * C + c];
+  const int S8 = S >> 3, total8 = N * S8;
+  u16x8 gv[IPT], yv[IPT];
+  size_t off[IPT];
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    const int t = threadIdx.x + u * NT;
+    const int tt = t < total8 ? t : 0;
+    const int n = tt / S8, i8 = tt - n * S8;
+    off[u] = ((size_t)n * C + c) * S + (size_t)i8 * 8;
+    gv[u] = *reinterpret_cast<const u16x8*>(g + off[u]);
+    yv[u] = *reinterpret_cast<const u16x8*>(y + off[u]);
+  }
+  float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    const bool in = threadIdx.x + u * NT < total8;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const float yy = msl::bf2f(yv[u][k]);
+      const bool on = in && fmaf(yy, sc, sh) > 0.f;
+      if (!on) gv[u][k] = 0;  // gm (bf16 zero)
+      const float gm = msl::bf2f(gv[u][k]);
+      s1 += gm;
+      s2 += gm * ((yy - mu) * is);
+    }
+  }
+  const double t1 = msl::block_sum((double)s1, scratch);
+  __syncthreads();
+  const double t2 = msl::block_sum((double)s2, scratch);
+  if (threadIdx.x == 0) {
+    dbeta[c] = (float)t1;
+    dgamma[c] = (float)t2;
+    coef[0] = (float)(t1 / count);
+    coef[1] = (float)(t2 / count);
+  }
+  __syncthreads();
+  const float k1 = coef[0], k2 = coef[1];
+#pragma unroll
+  for (int u = 0; u < IPT; ++u) {
+    if (threadIdx.x + u * NT < total8) {
+      u16x8 o;
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        o[k] = msl::f2bf(sc * (msl::bf2f(gv[u][k]) - k1 - ((msl::bf2f(yv[u][k]) - mu) * is) * k2));
+      *reinterpret_cast<u16x8*>(dy + off[u]) = o;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
 
+static bool dw_bf16_use_wave() {  // MSL_BF16_DW_WAVE=0: always the LDS-tiled any-shape kernels (A/B and tests)
+  static const int on = getenv("MSL_BF16_DW_WAVE") ? atoi(getenv("MSL_BF16_DW_WAVE")) : 1;
+  return on != 0;
+}
+
 int msl_dwconv_fwd_bf16_num_partials(int N, int C, int D, int H, int W, int stride) {
+  if (dw_bf16_use_wave()) {
+    const int np = msl_dwconv_wave_num_partials(N, C, D, H, W, stride);
+    if (np > 0) return np;
+  }
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   return N * msl::cdiv(OD, DW_TD) * msl::cdiv(OH, DW_TH) * msl::cdiv(OW, DW_TW);
 }
@@ -555,6 +650,8 @@ int msl_dwconv_fwd_bf16_num_partials(int N, int C, int D, int H, int W, int stri
 int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                         double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
+  if (dw_bf16_use_wave() && msl_dwconv_wave_num_partials(N, C, D, H, W, stride) > 0)
+    return msl_dwconv_fwd_wave_bf16(x, in_scale, in_shift, w, y, partials, N, C, D, H, W, stride, 0, 0, stream);
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   const int tiles_d = msl::cdiv(OD, DW_TD), tiles_h = msl::cdiv(OH, DW_TH), tiles_w = msl::cdiv(OW, DW_TW);
   const int NP = N * tiles_d * tiles_h * tiles_w;
@@ -595,6 +692,17 @@ int msl_bn_relu_materialize_bf16(const void* y, const float* scale, const float*
   dim3 grid(msl::cdiv(D * H * W, 256), C / 8, N);
   hipLaunchKernelGGL(materialize_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, plain,
                      (u16*)pad_cl, C, D, H, W);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// y (N,C,D,H,W) bf16 raw + affine -> pad (N,C,D+2,H+2,W+2) fp32 (halo pre-zeroed by the caller): what the fp32 head kernels read
+int msl_bn_relu_materialize_bf16_pad32(const void* y, const float* scale, const float* shift, float* pad, int N, int C, int D,
+                                       int H, int W, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !pad) return MSL_ERR_ARG;
+  dim3 grid(msl::cdiv(D * H * W, 256), C, N);
+  hipLaunchKernelGGL(materialize_bf16_pad32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, pad, C,
+                     D, H, W);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -664,6 +772,10 @@ int msl_dwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, 
                              int accumulate, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
+  if (stride == 1 && dw_bf16_use_wave() && msl_dwconv_wave_num_partials(N, C, D, H, W, 1) > 0)
+    return msl_dwconv_fwd_wave_bf16(dy, nullptr, nullptr, w, g_in, nullptr, N, C, D, H, W, 1, 1, accumulate, stream);
+  if (stride == 2 && dw_bf16_use_wave() && W % 4 == 0)
+    return msl_dwconv_bwd_data_s2_patch_bf16(dy, w, g_in, nullptr, nullptr, nullptr, N, C, D, H, W, accumulate, stream);
   if (stride == 1) {  // the forward kernel with reversed taps
     const int tiles_d = msl::cdiv(D, DW_TD), tiles_h = msl::cdiv(H, DW_TH), tiles_w = msl::cdiv(W, DW_TW);
     dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
@@ -684,6 +796,8 @@ int msl_dwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, 
 int msl_dwconv_bwd_weight_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift, double* partials,
                                int N, int C, int D, int H, int W, int stride, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || !partials) return MSL_ERR_ARG;
+  if (dw_bf16_use_wave() && msl_dwconv_wave_num_partials(N, C, D, H, W, stride) > 0)
+    return msl_dwconv_bwd_weight_wave_bf16(dz, x, in_scale, in_shift, partials, N, C, D, H, W, stride, stream);
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   const int tiles_d = msl::cdiv(OD, DW_TD), tiles_h = msl::cdiv(OH, DW_TH), tiles_w = msl::cdiv(OW, DW_TW);
   const int NP = N * tiles_d * tiles_h * tiles_w;
@@ -725,7 +839,23 @@ int msl_bn_relu_bwd_apply_bf16(const void* g, const void* y, const float* vec, v
 int msl_bn_relu_bwd_fused_bf16(const void* g, const void* y, const float* vec, float* dgamma, float* dbeta, void* dy, int N,
                                int C, int S, void* stream) {
   if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_relu_bwd_fused_bf16_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, (const u16*)g, (const u16*)y, vec,
+  hipStream_t st = (hipStream_t)stream;
+  const long long total8 = (long long)N * (S >> 3);
+#define MSL_BN_REG(NT_, IPT_)                                                                                              \
+  hipLaunchKernelGGL((bn_relu_bwd_fused_reg_bf16_kernel<NT_, IPT_>), dim3(C), dim3(NT_), 0, st, (const u16*)g, (const u16*)y, \
+                     vec, dgamma, dbeta, (u16*)dy, N, C, S, (double)N * (double)S)
+  if ((S & 7) == 0 && total8 <= 4096) {
+    if (total8 <= 64) MSL_BN_REG(64, 1);
+    else if (total8 <= 256) MSL_BN_REG(256, 1);
+    else if (total8 <= 512) MSL_BN_REG(256, 2);
+    else if (total8 <= 1024) MSL_BN_REG(512, 2);
+    else if (total8 <= 2048) MSL_BN_REG(1024, 2);
+    else MSL_BN_REG(1024, 4);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
+#undef MSL_BN_REG
+  hipLaunchKernelGGL(bn_relu_bwd_fused_bf16_kernel, dim3(C), dim3(256), 0, st, (const u16*)g, (const u16*)y, vec,
                      dgamma, dbeta, (u16*)dy, N, C, S, (double)N * (double)S);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

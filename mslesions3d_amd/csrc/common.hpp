@@ -142,6 +142,41 @@ __host__ __device__ __forceinline__ int cdiv(int a, int b) { return (a + b - 1) 
 __device__ __forceinline__ unsigned short f2bf(float v) { return __builtin_bit_cast(unsigned short, (__bf16)v); }
 __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
 
+// ---- activation storage: fp32 (the reference's precision) or bf16 (the bf16 activation path) -------------------------------
+// Kernels templated on the storage type T walk 4 (or 2, or 1) consecutive elements per lane either way; arithmetic is fp32.
+typedef unsigned short su16;
+typedef su16 su16x4 __attribute__((ext_vector_type(4)));
+typedef su16 su16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const su16* p) { return bf2f(*p); }
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const su16* p) {
+  const su16x4 v = *reinterpret_cast<const su16x4*>(p);
+  return make_float4(bf2f(v[0]), bf2f(v[1]), bf2f(v[2]), bf2f(v[3]));
+}
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const su16* p) {
+  const su16x2 v = *reinterpret_cast<const su16x2*>(p);
+  return make_float2(bf2f(v[0]), bf2f(v[1]));
+}
+__device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void st4(su16* p, float4 v) {
+  su16x4 o;
+  o[0] = f2bf(v.x); o[1] = f2bf(v.y); o[2] = f2bf(v.z); o[3] = f2bf(v.w);
+  *reinterpret_cast<su16x4*>(p) = o;
+}
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void st2(su16* p, float2 v) {
+  su16x2 o;
+  o[0] = f2bf(v.x); o[1] = f2bf(v.y);
+  *reinterpret_cast<su16x2*>(p) = o;
+}
+// the value a later pass will read back from storage (bf16: rounded once)
+__device__ __forceinline__ float4 as_stored(const float*, float4 v) { return v; }
+__device__ __forceinline__ float4 as_stored(const su16*, float4 v) {
+  return make_float4(bf2f(f2bf(v.x)), bf2f(f2bf(v.y)), bf2f(f2bf(v.z)), bf2f(f2bf(v.w)));
+}
+
 // ---- BatchNorm fold -------------------------------------------------------------------------------------------
 // Turning the fp64 (sum, sumsq) partials of a producer into its per-channel affine is cheap, but as a kernel of its
 // own it sits on the forward dependency chain (15 launches of ~6 us).  So the CONSUMER kernels fold the partials of

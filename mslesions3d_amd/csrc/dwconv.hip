@@ -555,6 +555,12 @@ __global__ __launch_bounds__(256) void dw_fwd_resident_kernel(
 // the lane W/4 away and the column neighbours sit in the adjacent lanes, so the 3x3 window comes from DPP lane
 // shifts (ds_bpermute for the 16x16 plane, whose 4-lane rows cross the 16-lane DPP rows).  No LDS tile, no
 // barrier, no integer division per element; waves are independent.
+using msl::ld2;
+using msl::ld4;
+using msl::st2;
+using msl::st4;
+typedef msl::su16 dwu16;  // bf16 storage (see common.hpp)
+
 template <int S>
 __device__ __forceinline__ float lane_minus(float v, int lane) {  // value held by lane - S (caller masks lanes without one)
   if constexpr (S == 1) return msl::dpp_mov<0x111>(v);       // row_shr:1
@@ -568,10 +574,10 @@ __device__ __forceinline__ float lane_plus(float v, int lane) {
   else return __int_as_float(__builtin_amdgcn_ds_bpermute(((lane + S) & 63) << 2, __float_as_int(v)));
 }
 
-template <int LOGW4, int LOGH, int SL>
+template <int LOGW4, int LOGH, int SL, typename T = float>
 __global__ __launch_bounds__(256) void dw_s1_wave_kernel(
-    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int nslabs,
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ w, T* __restrict__ y, double* __restrict__ partials, int C, int D, int nslabs,
     int Nbatch, int flip, int accumulate, msl::BnFold fold) {
   constexpr int W4 = 1 << LOGW4, H = 1 << LOGH, P4 = W4 * H, CPW = 64 / P4, W = 4 * W4, HW = H * W, NPL = SL + 2;
   const int lane = threadIdx.x & 63;
@@ -586,12 +592,12 @@ __global__ __launch_bounds__(256) void dw_s1_wave_kernel(
   const int od0 = slab * SL;
 
   // every input plane of the wave leaves first (unconditional, on clamped plane indices; masked below)
-  const float* xc = x + (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
+  const T* xc = x + (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
   float4 pv[NPL];
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int p = min(max(od0 - 1 + i, 0), D - 1);
-    pv[i] = *reinterpret_cast<const float4*>(xc + (size_t)p * HW);
+    pv[i] = ld4(xc + (size_t)p * HW);
   }
   float wk[27];  // CPW == 1: the channel is wave-uniform and the taps are scalar loads
 #pragma unroll
@@ -677,17 +683,17 @@ __global__ __launch_bounds__(256) void dw_s1_wave_kernel(
   }
 
   double ds = 0.0, dq = 0.0;
-  float* yc = y + (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
+  T* yc = y + (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
 #pragma unroll
   for (int o = 0; o < SL; ++o) {
     const int od = od0 + o;
     if (od >= D) continue;  // wave-uniform (ragged last slab)
-    float* yo = yc + (size_t)od * HW;
+    T* yo = yc + (size_t)od * HW;
     if (accumulate) {
-      const float4 old = *reinterpret_cast<const float4*>(yo);
+      const float4 old = ld4(yo);
       acc[o][0] += old.x; acc[o][1] += old.y; acc[o][2] += old.z; acc[o][3] += old.w;
     }
-    *reinterpret_cast<float4*>(yo) = make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]);
+    st4(yo, make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]));
     float s = 0.f, q = 0.f;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
@@ -726,10 +732,10 @@ constexpr int s2_wave_block() {  // threads per workgroup: up to four waves of a
   return (1 << (LOGW4 + LOGOH)) == 128 ? 128 : 256;
 }
 
-template <int LOGW4, int LOGOH, int SL>
+template <int LOGW4, int LOGOH, int SL, typename T = float>
 __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_kernel(
-    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* __restrict__ w, float* __restrict__ y, double* __restrict__ partials, int C, int D, int OD,
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const float* __restrict__ w, T* __restrict__ y, double* __restrict__ partials, int C, int D, int OD,
     int nslabs, int Nbatch, msl::BnFold fold) {
   constexpr int W4 = 1 << LOGW4, OH = 1 << LOGOH, LOGC = LOGW4 + LOGOH, CELLS = 1 << LOGC;
   constexpr int CPW = CELLS >= 64 ? 1 : 64 / CELLS, WPP = CELLS >= 64 ? CELLS / 64 : 1;
@@ -752,16 +758,16 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_ke
   const int od0 = slab * SL;
   const bool up_ok = oh > 0, lf_ok = w4 > 0;
 
-  const float* xc = x + (size_t)(n * C + c) * D * HW + w4 * 4;
+  const T* xc = x + (size_t)(n * C + c) * D * HW + w4 * 4;
   const int row_m = (up_ok ? 2 * oh - 1 : 0) * W, row_0 = 2 * oh * W;
   float4 pv[NPL][3];
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int p = min(max(2 * od0 - 1 + i, 0), D - 1);
-    const float* xp = xc + (size_t)p * HW;
-    pv[i][0] = *reinterpret_cast<const float4*>(xp + row_m);
-    pv[i][1] = *reinterpret_cast<const float4*>(xp + row_0);
-    pv[i][2] = *reinterpret_cast<const float4*>(xp + row_0 + W);
+    const T* xp = xc + (size_t)p * HW;
+    pv[i][0] = ld4(xp + row_m);
+    pv[i][1] = ld4(xp + row_0);
+    pv[i][2] = ld4(xp + row_0 + W);
   }
   float wk[27];
 #pragma unroll
@@ -801,7 +807,7 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_ke
   for (int i = 0; i < NPL; ++i) {
     const int p = 2 * od0 - 1 + i;
     if (p < 0 || p >= D) continue;  // wave-uniform
-    float T[3][5];  // T[kh][0..4] = columns 4*w4-1 .. 4*w4+3 of input row 2*oh-1+kh
+    float Tr[3][5];  // Tr[kh][0..4] = columns 4*w4-1 .. 4*w4+3 of input row 2*oh-1+kh
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       float4 m = pv[i][r];
@@ -812,12 +818,12 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_ke
       if (r == 0) {  // the row above the first output row is padding
         m.x = up_ok ? m.x : 0.f; m.y = up_ok ? m.y : 0.f; m.z = up_ok ? m.z : 0.f; m.w = up_ok ? m.w : 0.f;
       }
-      T[r][1] = m.x; T[r][2] = m.y; T[r][3] = m.z; T[r][4] = m.w;
+      Tr[r][1] = m.x; Tr[r][2] = m.y; Tr[r][3] = m.z; Tr[r][4] = m.w;
       if constexpr (W4 > 1) {
         const float l = lane_minus<1>(m.w, lane);
-        T[r][0] = lf_ok ? l : 0.f;
+        Tr[r][0] = lf_ok ? l : 0.f;
       } else {
-        T[r][0] = 0.f;
+        Tr[r][0] = 0.f;
       }
     }
 #pragma unroll
@@ -830,19 +836,19 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_ke
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) {
           const float ww = wk[kd * 9 + kh * 3 + kw];
-          acc[o][0] = fmaf(ww, T[kh][kw], acc[o][0]);
-          acc[o][1] = fmaf(ww, T[kh][kw + 2], acc[o][1]);
+          acc[o][0] = fmaf(ww, Tr[kh][kw], acc[o][0]);
+          acc[o][1] = fmaf(ww, Tr[kh][kw + 2], acc[o][1]);
         }
     }
   }
 
   double ds = 0.0, dq = 0.0;
-  float* yc = y + (size_t)(n * C + c) * OD * OHW + oh * OW + 2 * w4;
+  T* yc = y + (size_t)(n * C + c) * OD * OHW + oh * OW + 2 * w4;
 #pragma unroll
   for (int o = 0; o < SL; ++o) {
     const int od = od0 + o;
     if (od >= OD) continue;  // wave-uniform (ragged last slab)
-    *reinterpret_cast<float2*>(yc + (size_t)od * OHW) = make_float2(acc[o][0], acc[o][1]);
+    st2(yc + (size_t)od * OHW, make_float2(acc[o][0], acc[o][1]));
     const float s = acc[o][0] + acc[o][1];
     const float q = fmaf(acc[o][1], acc[o][1], acc[o][0] * acc[o][0]);
     ds += (double)s;
@@ -920,10 +926,10 @@ __device__ __forceinline__ double group_sum(double v, int lane) {  // sum over e
   }
 }
 
-template <int LOGW4, int LOGH, int SL>
+template <int LOGW4, int LOGH, int SL, typename T = float>
 __global__ __launch_bounds__(256) void dw_s1_wave_bww_kernel(
-    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* __restrict__ dy, double* __restrict__ partials, int C, int D, int nslabs, int Nbatch) {
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const T* __restrict__ dy, double* __restrict__ partials, int C, int D, int nslabs, int Nbatch) {
   constexpr int W4 = 1 << LOGW4, H = 1 << LOGH, P4 = W4 * H, CPW = 64 / P4, W = 4 * W4, HW = H * W, NPL = SL + 2;
   const int lane = threadIdx.x & 63;
   const int gw = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -941,12 +947,12 @@ __global__ __launch_bounds__(256) void dw_s1_wave_bww_kernel(
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int p = min(max(od0 - 1 + i, 0), D - 1);
-    pv[i] = *reinterpret_cast<const float4*>(x + cell + (size_t)p * HW);
+    pv[i] = ld4(x + cell + (size_t)p * HW);
   }
 #pragma unroll
   for (int o = 0; o < SL; ++o) {
     const int od = min(od0 + o, D - 1);
-    dv[o] = *reinterpret_cast<const float4*>(dy + cell + (size_t)od * HW);
+    dv[o] = ld4(dy + cell + (size_t)od * HW);
   }
   const bool affine = in_scale != nullptr;
   const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
@@ -1014,10 +1020,10 @@ __global__ __launch_bounds__(256) void dw_s1_wave_bww_kernel(
   }
 }
 
-template <int LOGW4, int LOGOH, int SL>
+template <int LOGW4, int LOGOH, int SL, typename T = float>
 __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_bww_kernel(
-    const float* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
-    const float* __restrict__ dy, double* __restrict__ partials, int C, int D, int OD, int nslabs, int Nbatch) {
+    const T* __restrict__ x, const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+    const T* __restrict__ dy, double* __restrict__ partials, int C, int D, int OD, int nslabs, int Nbatch) {
   constexpr int W4 = 1 << LOGW4, OH = 1 << LOGOH, LOGC = LOGW4 + LOGOH, CELLS = 1 << LOGC;
   constexpr int CPW = CELLS >= 64 ? 1 : 64 / CELLS, WPP = CELLS >= 64 ? CELLS / 64 : 1;
   constexpr int W = 4 * W4, H = 2 * OH, HW = H * W, OW = 2 * W4, OHW = OH * OW, NPL = 2 * SL + 1;
@@ -1036,23 +1042,23 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_bw
   const int od0 = slab * SL;
   const bool up_ok = oh > 0, lf_ok = w4 > 0;
 
-  const float* xc = x + (size_t)(n * C + c) * D * HW + w4 * 4;
+  const T* xc = x + (size_t)(n * C + c) * D * HW + w4 * 4;
   const int row_m = (up_ok ? 2 * oh - 1 : 0) * W, row_0 = 2 * oh * W;
   float4 pv[NPL][3];
   float2 dv[SL];
 #pragma unroll
   for (int i = 0; i < NPL; ++i) {
     const int p = min(max(2 * od0 - 1 + i, 0), D - 1);
-    const float* xp = xc + (size_t)p * HW;
-    pv[i][0] = *reinterpret_cast<const float4*>(xp + row_m);
-    pv[i][1] = *reinterpret_cast<const float4*>(xp + row_0);
-    pv[i][2] = *reinterpret_cast<const float4*>(xp + row_0 + W);
+    const T* xp = xc + (size_t)p * HW;
+    pv[i][0] = ld4(xp + row_m);
+    pv[i][1] = ld4(xp + row_0);
+    pv[i][2] = ld4(xp + row_0 + W);
   }
-  const float* dyc = dy + (size_t)(n * C + c) * OD * OHW + oh * OW + 2 * w4;
+  const T* dyc = dy + (size_t)(n * C + c) * OD * OHW + oh * OW + 2 * w4;
 #pragma unroll
   for (int o = 0; o < SL; ++o) {
     const int od = min(od0 + o, OD - 1);
-    dv[o] = *reinterpret_cast<const float2*>(dyc + (size_t)od * OHW);
+    dv[o] = ld2(dyc + (size_t)od * OHW);
   }
   const bool affine = in_scale != nullptr;
   const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
@@ -1073,7 +1079,7 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_bw
   for (int i = 0; i < NPL; ++i) {
     const int p = 2 * od0 - 1 + i;
     if (p < 0 || p >= D) continue;  // wave-uniform
-    float T[3][5];
+    float Tr[3][5];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       float4 m = pv[i][r];
@@ -1084,12 +1090,12 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_bw
       if (r == 0) {
         m.x = up_ok ? m.x : 0.f; m.y = up_ok ? m.y : 0.f; m.z = up_ok ? m.z : 0.f; m.w = up_ok ? m.w : 0.f;
       }
-      T[r][1] = m.x; T[r][2] = m.y; T[r][3] = m.z; T[r][4] = m.w;
+      Tr[r][1] = m.x; Tr[r][2] = m.y; Tr[r][3] = m.z; Tr[r][4] = m.w;
       if constexpr (W4 > 1) {
         const float l = lane_minus<1>(m.w, lane);
-        T[r][0] = lf_ok ? l : 0.f;
+        Tr[r][0] = lf_ok ? l : 0.f;
       } else {
-        T[r][0] = 0.f;
+        Tr[r][0] = 0.f;
       }
     }
 #pragma unroll
@@ -1101,7 +1107,7 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_bw
 #pragma unroll
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-        for (int kw = 0; kw < 3; ++kw) a27[kd * 9 + kh * 3 + kw] += fmaf(d.y, T[kh][kw + 2], d.x * T[kh][kw]);
+        for (int kw = 0; kw < 3; ++kw) a27[kd * 9 + kh * 3 + kw] += fmaf(d.y, Tr[kh][kw + 2], d.x * Tr[kh][kw]);
     }
   }
   if constexpr (WPP > 1) {
@@ -1321,20 +1327,21 @@ WavePlan make_wave_plan(int N, int C, int D, int H, int W, int stride) {
   return wp;
 }
 
-void launch_wave(const WavePlan& wp, const float* x, const float* in_scale, const float* in_shift, const float* w,
-                 float* y, double* partials, int N, int C, int D, int flip, int accumulate, const msl::BnFold& fold,
+template <typename T>
+void launch_wave(const WavePlan& wp, const T* x, const float* in_scale, const float* in_shift, const float* w,
+                 T* y, double* partials, int N, int C, int D, int flip, int accumulate, const msl::BnFold& fold,
                  hipStream_t st) {
   const int waves = N * (C / wp.cpw) * wp.nslabs;
   const dim3 grid(msl::cdiv(waves, 4)), block(256);
 #define MSL_DW_WAVE_SL(LW_, LH_)                                                                                  \
   switch (wp.SL) {                                                                                                \
-    case 8: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 8>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    case 8: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 8, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
-    case 4: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    case 4: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
-    case 2: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    case 2: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
-    default: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    default: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                 partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                     \
   }
   if (wp.logw4 == 0) { MSL_DW_WAVE_SL(0, 2) }
@@ -1343,18 +1350,19 @@ void launch_wave(const WavePlan& wp, const float* x, const float* in_scale, cons
 #undef MSL_DW_WAVE_SL
 }
 
-void launch_wave_s2(const WavePlan& wp, const float* x, const float* in_scale, const float* in_shift, const float* w,
-                    float* y, double* partials, int N, int C, int D, const msl::BnFold& fold, hipStream_t st) {
+template <typename T>
+void launch_wave_s2(const WavePlan& wp, const T* x, const float* in_scale, const float* in_shift, const float* w,
+                    T* y, double* partials, int N, int C, int D, const msl::BnFold& fold, hipStream_t st) {
   const int waves = N * (C / wp.cpw) * wp.nslabs * wp.wpp, OD = (D - 1) / 2 + 1;
   const int wpg = wp.wpp > 1 ? std::min(wp.wpp, 4) : 4;
   const dim3 grid(msl::cdiv(waves, wpg)), block(64 * wpg);
 #define MSL_DW_WAVE2_SL(LW_, LH_)                                                                                  \
   switch (wp.SL) {                                                                                                 \
-    case 4: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
+    case 4: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
                                partials, C, D, OD, wp.nslabs, N, fold); break;                                     \
-    case 2: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
+    case 2: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
                                partials, C, D, OD, wp.nslabs, N, fold); break;                                     \
-    default: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    default: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                 partials, C, D, OD, wp.nslabs, N, fold); break;                                    \
   }
   if (wp.logw4 == 1) { MSL_DW_WAVE2_SL(1, 2) }
@@ -1372,20 +1380,21 @@ bool wave_bww_enabled() {
 
 int wave_bww_num_partials(const WavePlan& wp, int N) { return N * wp.nslabs * (wp.wpp > 4 ? wp.wpp / 4 : 1); }
 
-void launch_wave_bww(const WavePlan& wp, int stride, const float* x, const float* in_scale, const float* in_shift,
-                     const float* dy, double* partials, int N, int C, int D, hipStream_t st) {
+template <typename T>
+void launch_wave_bww(const WavePlan& wp, int stride, const T* x, const float* in_scale, const float* in_shift,
+                     const T* dy, double* partials, int N, int C, int D, hipStream_t st) {
   const int waves = N * (C / wp.cpw) * wp.nslabs * wp.wpp;
   if (stride == 1) {
     const dim3 grid(msl::cdiv(waves, 4)), block(256);
 #define MSL_DW_WAVE_BWW1(LW_, LH_)                                                                                \
   switch (wp.SL) {                                                                                                \
-    case 8: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 8>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 8: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 8, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, wp.nslabs, N); break;                                          \
-    case 4: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 4: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, wp.nslabs, N); break;                                          \
-    case 2: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 2: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, wp.nslabs, N); break;                                          \
-    default: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift,  \
+    default: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift,  \
                                 dy, partials, C, D, wp.nslabs, N); break;                                         \
   }
     if (wp.logw4 == 0) { MSL_DW_WAVE_BWW1(0, 2) }
@@ -1398,11 +1407,11 @@ void launch_wave_bww(const WavePlan& wp, int stride, const float* x, const float
   const dim3 grid(msl::cdiv(waves, wpg)), block(64 * wpg);
 #define MSL_DW_WAVE_BWW2(LW_, LH_)                                                                                \
   switch (wp.SL) {                                                                                                \
-    case 4: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 4>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 4: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, OD, wp.nslabs, N); break;                                      \
-    case 2: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 2>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 2: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, OD, wp.nslabs, N); break;                                      \
-    default: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 1>), grid, block, 0, st, x, in_scale, in_shift,  \
+    default: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift,  \
                                 dy, partials, C, D, OD, wp.nslabs, N); break;                                     \
   }
   if (wp.logw4 == 1) { MSL_DW_WAVE_BWW2(1, 2) }
@@ -1438,9 +1447,48 @@ int msl_dwconv_fwd_variant(int N, int C, int D, int H, int W, int stride) {
   return make_plan(N, C, D, H, W, stride).variant;
 }
 
+static const msl::BnFold nofold{nullptr, 0, 0, 1.0, nullptr, nullptr, 0.f};
+
+// ---- bf16 storage on the wave kernels (the bf16 activation path, bf16.hip, tries these first) ---------------------------
+// number of statistics / weight-gradient partials per channel, or MSL_ERR_UNSUPPORTED when the shape has no wave plan
+int msl_dwconv_wave_num_partials(int N, int C, int D, int H, int W, int stride) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
+  const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+  return wp.ok ? N * wp.nslabs * (wp.wpp > 4 ? wp.wpp / 4 : 1) : MSL_ERR_UNSUPPORTED;
+}
+
+// x (N,C,D,H,W) bf16 raw (+ input affine) -> y bf16 raw (+ fp64 statistics partials [2][C][NP] from the fp32 accumulators);
+// flip: reversed taps (stride-1 bwd-data), accumulate: y += result
+int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
+                             double* partials, int N, int C, int D, int H, int W, int stride, int flip, int accumulate,
+                             void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
+  const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+  if (!wp.ok || (stride == 2 && (flip || accumulate))) return MSL_ERR_UNSUPPORTED;
+  if (stride == 1)
+    launch_wave(wp, reinterpret_cast<const dwu16*>(x), in_scale, in_shift, w, reinterpret_cast<dwu16*>(y), partials, N, C, D, flip,
+                accumulate, nofold, (hipStream_t)stream);
+  else
+    launch_wave_s2(wp, reinterpret_cast<const dwu16*>(x), in_scale, in_shift, w, reinterpret_cast<dwu16*>(y), partials, N, C, D,
+                   nofold, (hipStream_t)stream);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// dz (N,C,OD,OH,OW), x (N,C,D,H,W) bf16 (+ input affine) -> fp64 partials [C*27][NP], NP = msl_dwconv_wave_num_partials
+int msl_dwconv_bwd_weight_wave_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift,
+                                    double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || !partials) return MSL_ERR_ARG;
+  const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+  if (!wp.ok) return MSL_ERR_UNSUPPORTED;
+  launch_wave_bww(wp, stride, reinterpret_cast<const dwu16*>(x), in_scale, in_shift, reinterpret_cast<const dwu16*>(dz), partials,
+                  N, C, D, (hipStream_t)stream);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
 // bwd-weight on the LDS-tiled kernels (MODE 1).  Returns MSL_ERR_UNSUPPORTED for shapes on the generic path.
 // partials: fp64 [C*27][NP], NP = msl_dwconv_bwd_weight_num_partials().
-static const msl::BnFold nofold{nullptr, 0, 0, 1.0, nullptr, nullptr, 0.f};
 
 int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in_scale, const float* in_shift,
                                 double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {

@@ -124,12 +124,12 @@ __global__ __launch_bounds__(256) void dw_bwd_data_kernel(const float* __restric
 // per channel.  The kernel already holds every g value in registers, so it reads y_prev at the same 16 positions
 // and emits the fp64 partials itself: the separate reduce pass (a second read of the 134 MB gradient at block 1)
 // disappears.
-template <bool REDUCE>
-__global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* __restrict__ dy,
+template <bool REDUCE, typename T = float>
+__global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const T* __restrict__ dy,
                                                                    const float* __restrict__ w,
-                                                                   float* __restrict__ g_in, int C, int D, int H, int W,
+                                                                   T* __restrict__ g_in, int C, int D, int H, int W,
                                                                    int OD, int OH, int OW, int accumulate,
-                                                                   const float* __restrict__ y_prev,
+                                                                   const T* __restrict__ y_prev,
                                                                    const float* __restrict__ bn_scale,
                                                                    const float* __restrict__ bn_shift,
                                                                    const float* __restrict__ bn_mean,
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
   float wk[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) wk[k] = w[c * 27 + k];
-  const float* dyc = dy + (size_t)nc * OD * OH * OW;
+  const T* dyc = dy + (size_t)nc * OD * OH * OW;
   // every global read of the thread is issued here, unconditionally on clamped addresses (masked afterwards), so
   // they share one memory round trip: the 12 gradients, and the 4 destination rows' previous gradient (accumulate)
   // and forward value (REDUCE)
@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
 #pragma unroll
       for (int ww = 0; ww < 3; ++ww) {
         const bool ok = a + dd < OD && b + hh < OH && c2 + ww < OW;
-        const float v = dyc[ok ? ((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww : 0];
+        const float v = msl::ld1(dyc + (ok ? ((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww : 0));
         dv[dd][hh][ww] = ok ? v : 0.f;
       }
   bool okp[2][2];
@@ -172,13 +172,13 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
       const int id = 2 * a + pd, ih = 2 * b + ph;
       okp[pd][ph] = live && id < D && ih < H;
       offp[pd][ph] = (size_t)nc * D * H * W + (okp[pd][ph] ? ((size_t)id * H + ih) * W + iw0 : 0);
-      if (REDUCE) yv[pd][ph] = *reinterpret_cast<const float4*>(y_prev + offp[pd][ph]);
+      if (REDUCE) yv[pd][ph] = msl::ld4(y_prev + offp[pd][ph]);
     }
   if (accumulate) {
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
 #pragma unroll
-      for (int ph = 0; ph < 2; ++ph) old[pd][ph] = *reinterpret_cast<const float4*>(g_in + offp[pd][ph]);
+      for (int ph = 0; ph < 2; ++ph) old[pd][ph] = msl::ld4(g_in + offp[pd][ph]);
   } else {
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
@@ -215,7 +215,6 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
       }
       g[pd][ph][0] = o0; g[pd][ph][1] = o1; g[pd][ph][2] = o2; g[pd][ph][3] = o3;
     }
-  float* base = g_in + (size_t)nc * D * H * W;
   float s1 = 0.f, s2 = 0.f;
   float sc = 0.f, sh = 0.f, mu = 0.f, is = 0.f;
   if (REDUCE) {
@@ -227,8 +226,9 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
     for (int ph = 0; ph < 2; ++ph) {
       if (okp[pd][ph]) {
         const float4 o = old[pd][ph];
-        const float4 v = make_float4(g[pd][ph][0] + o.x, g[pd][ph][1] + o.y, g[pd][ph][2] + o.z, g[pd][ph][3] + o.w);
-        *reinterpret_cast<float4*>(g_in + offp[pd][ph]) = v;
+        float4 v = make_float4(g[pd][ph][0] + o.x, g[pd][ph][1] + o.y, g[pd][ph][2] + o.z, g[pd][ph][3] + o.w);
+        msl::st4(g_in + offp[pd][ph], v);
+        if (REDUCE) v = msl::as_stored(g_in, v);  // the sums must see what the apply pass will read back
         if (REDUCE) {
           const float4 y4 = yv[pd][ph];
           const float ga[4] = {v.x, v.y, v.z, v.w}, ya[4] = {y4.x, y4.y, y4.z, y4.w};
@@ -241,7 +241,6 @@ __global__ __launch_bounds__(256) void dw_bwd_data_s2_patch_kernel(const float* 
         }
       }
     }
-  (void)base;
   if (REDUCE) {
     const int NP = (gridDim.y / C) * gridDim.x, p = (nc / C) * gridDim.x + blockIdx.x;
     const double t1 = msl::block_sum((double)s1, scratch);
@@ -498,8 +497,8 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
   if (W % 4 == 0) {
     if (stride == 2) {
       dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
-      hipLaunchKernelGGL(dw_bwd_data_s2_patch_kernel<false>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW,
-                         accumulate, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<false, float>), grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW,
+                         accumulate, (const float*)nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     } else {
       dim3 grid(msl::cdiv(D * H * (W / 4), 256), N * C);
       hipLaunchKernelGGL(dw_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
@@ -528,8 +527,32 @@ int msl_dwconv_bwd_data_bnreduce(const float* dy, const float* w, float* g_in, c
   if (stride != 2 || W % 4 != 0) return MSL_ERR_UNSUPPORTED;
   const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
-  hipLaunchKernelGGL(dw_bwd_data_s2_patch_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, dy, w, g_in, C, D, H, W,
+  hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<true, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, g_in, C, D, H, W,
                      OD, OH, OW, accumulate, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, partials);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// ---- bf16 storage (the bf16 activation path): the stride-2 patch kernel on bf16 gradients ---------------------------------
+// y_prev != NULL: also emit the BatchNorm-backward partials [2][C][NP] (NP = msl_dwconv_bwd_data_bnreduce_num_partials) of the
+// layer whose activation gradient is written, computed from the ROUNDED gradient.  W % 4 == 0, else MSL_ERR_UNSUPPORTED.
+int msl_dwconv_bwd_data_s2_patch_bf16(const void* dy, const float* w, void* g_in, const void* y_prev, const float* bn_vec,
+                                      double* partials, int N, int C, int D, int H, int W, int accumulate, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0) return MSL_ERR_ARG;
+  if (W % 4 != 0) return MSL_ERR_UNSUPPORTED;
+  const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
+  typedef msl::su16 u16;
+  if (y_prev) {
+    if (!bn_vec || !partials) return MSL_ERR_ARG;
+    hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<true, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w,
+                       (u16*)g_in, C, D, H, W, OD, OH, OW, accumulate, (const u16*)y_prev, bn_vec, bn_vec + C, bn_vec + 2 * C,
+                       bn_vec + 3 * C, partials);
+  } else {
+    hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<false, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w,
+                       (u16*)g_in, C, D, H, W, OD, OH, OW, accumulate, (const u16*)nullptr, nullptr, nullptr, nullptr, nullptr,
+                       nullptr);
+  }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -236,6 +236,10 @@ class Engine:
         self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
         self.extra = {}
         self.early_pw_bww = os.environ.get("MSL_EARLY_PW_BWW", "0") == "1"
+        # an event record costs the chain ~6 us (the next kernel waits for the barrier packet): the weight gradients of
+        # several blocks can share one record, at the price of starting up to that many blocks later
+        e = os.environ.get("MSL_WGRAD_RECORD_AT")
+        self.wgrad_record_at = None if e is None else {int(v) for v in e.split(",") if v.strip()}
         # the weight gradients of block i are enqueued after the chain launches of block i - wgrad_lag (host enqueue order
         # only; on the device they wait for their events): a larger lag keeps the dependency chain's queue ahead of the GPU
         self.wgrad_lag = int(os.environ.get("MSL_WGRAD_LAG", "1"))
@@ -542,8 +546,11 @@ class Engine:
             D, H, W = pl.dims[f]
             off += D * H * W * m.boxes_per_location
         pl.P = off
-        pl.fpad_cl = {f: torch.zeros((N,) + tuple(d + 2 for d in pl.dims[f]) + (specs[f]["cout"],), **bf) for f in pl.feat_ids}
-        pl.Wp = {f: torch.empty(L.msl_head_packed_weight_bf16_elems(specs[f]["cout"]), **bf) for f in pl.feat_ids}
+        if need_grad:  # the training step runs its head convolutions on the fp32 kernels (faster at these sizes)
+            pl.fpad = {f: torch.zeros((N, specs[f]["cout"]) + tuple(d + 2 for d in pl.dims[f]), **f32) for f in pl.feat_ids}
+        else:
+            pl.fpad_cl = {f: torch.zeros((N,) + tuple(d + 2 for d in pl.dims[f]) + (specs[f]["cout"],), **bf) for f in pl.feat_ids}
+            pl.Wp = {f: torch.empty(L.msl_head_packed_weight_bf16_elems(specs[f]["cout"]), **bf) for f in pl.feat_ids}
         pl.locs = torch.empty((N, pl.P, 6), **f32)
         pl.scores = torch.empty((N, pl.P, ncls), **f32)
         pl.nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -558,7 +565,8 @@ class Engine:
                 C = specs[f]["cout"]
                 ne = L.msl_head_packed_weight_elems(C, ncls)
                 pl.Wf[f], pl.Wb[f] = torch.empty(ne, **f32), torch.empty(ne, **f32)
-                ws = L.msl_head_bwd_weight_workspace_bytes(N, C, *pl.dims[f], ncls)
+                ws = max(L.msl_head_fwd_workspace_bytes(N, C, *pl.dims[f], ncls),
+                         L.msl_head_bwd_weight_workspace_bytes(N, C, *pl.dims[f], ncls))
                 pl.head_ws[f] = torch.empty(max(ws // 4, 1), **f32)
             pl.head_nslabs = {f: L.msl_head_conv_bwd_weight_nslabs(N, specs[f]["cout"], *pl.dims[f], ncls) for f in pl.feat_ids}
             pl.ws_stem = torch.empty(max(L.msl_stem_conv_bwd_weight_workspace_bytes(specs[0]["cin"]) // 4, 1), **f32)
@@ -576,7 +584,8 @@ class Engine:
                 pl.dw_np.append(pl.np_z[i])
                 pl.dw_part.append(torch.empty(specs[i]["cin"] * 27 * pl.np_z[i], **f64))
                 bnp = max(bnp, 2 * specs[i]["cout"] * L.msl_bn_relu_bwd_bf16_num_partials(N, D * H * W),
-                          2 * specs[i]["cin"] * L.msl_bn_relu_bwd_bf16_num_partials(N, D * H * W))
+                          2 * specs[i]["cin"] * L.msl_bn_relu_bwd_bf16_num_partials(N, D * H * W),
+                          2 * specs[i]["cin"] * max(L.msl_dwconv_bwd_data_bnreduce_num_partials(N, specs[i]["cin"], pd, ph, pw), 0))
             d0 = pl.dims[0]
             bnp = max(bnp, 2 * specs[0]["cout"] * L.msl_bn_relu_bwd_bf16_num_partials(N, d0[0] * d0[1] * d0[2]))
             pl.partials = torch.empty(bnp, **f64)
@@ -627,7 +636,13 @@ class Engine:
                     ptr(blk.conv2.weight), ptr(pl.y[i]), part(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
             if training:
                 self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
-            if i in pl.fpad_cl:
+            if i in pl.feat_ids and need_grad:
+                self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16_pad32", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
+                        ptr(pl.bn_y[i][1]), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
+                if want_features:
+                    out_feats[i] = pl.fpad[i][:, :, 1:-1, 1:-1, 1:-1].clone()
+                self._head_forward(pl, i, st)
+            elif i in pl.feat_ids:
                 plain = None
                 if want_features:
                     plain = out_feats[i] = torch.empty((N, sp["cout"], D, H, W), dtype=torch.float32, device=x.device)
@@ -646,17 +661,24 @@ class Engine:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores
 
-    def _bn_bwd_bf16(self, g, y, vec, bn_name, N, C, S, pl, st):
-        """In place: g (bf16, = dL/d relu(bn(y))) becomes dL/dy; dgamma / dbeta into the gradient arena."""
+    @staticmethod
+    def _bn_bwd_bf16_fused(N, S):
+        """One launch (the channel's data held in registers) instead of reduce + finalize + apply?"""
+        return (N * S <= 32768 and S % 8 == 0) or N * S <= 4096
+
+    def _bn_bwd_bf16(self, g, y, vec, bn_name, N, C, S, pl, st, pre_np=None):
+        """In place: g (bf16, = dL/d relu(bn(y))) becomes dL/dy; dgamma / dbeta into the gradient arena.
+        ``pre_np``: the producer of g already left that many reduce partials per channel in pl.partials."""
         L = _lib.load()
         gv = self.arena.grad_views
-        if N * S <= 65536:
+        if pre_np is None and self._bn_bwd_bf16_fused(N, S):
             self._k("bn_bwd_fused:" + bn_name, "msl_bn_relu_bwd_fused_bf16", ptr(g), ptr(y), ptr(vec), ptr(gv[bn_name + ".weight"]),
                     ptr(gv[bn_name + ".bias"]), ptr(g), N, C, S, st)
             return
-        NP = L.msl_bn_relu_bwd_bf16_num_partials(N, S)
-        self._k("bn_bwd_reduce:" + bn_name, "msl_bn_relu_bwd_reduce_bf16", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
-                ptr(vec[3]), ptr(pl.partials), N, C, S, st)
+        NP = pre_np if pre_np is not None else L.msl_bn_relu_bwd_bf16_num_partials(N, S)
+        if pre_np is None:
+            self._k("bn_bwd_reduce:" + bn_name, "msl_bn_relu_bwd_reduce_bf16", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]),
+                    ptr(vec[3]), ptr(pl.partials), N, C, S, st)
         _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(N * S), ptr(gv[bn_name + ".weight"]),
                   ptr(gv[bn_name + ".bias"]), ptr(vec[4]), ptr(vec[5]), C, st)
         self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply_bf16", ptr(g), ptr(y), ptr(vec), ptr(g), N, C, S, st)
@@ -670,6 +692,8 @@ class Engine:
         N, ncls = pl.N, m.n_classes
         dlocs, dscores = dlocs.contiguous(), dscores.contiguous()
         last = len(specs) - 1
+        L = _lib.load()
+        pre_np = None
         for k, f in enumerate(pl.feat_ids):
             C = specs[f]["cout"]
             D, H, W = pl.dims[f]
@@ -677,7 +701,7 @@ class Engine:
                     pl.prior_off[f], ncls, st)
             self._k(f"head_bwd{f}", "msl_head_conv_bwd_data_bf16", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W,
                     ncls, st)
-            self._k(f"head_bww{f}", "msl_head_conv_bwd_weight_bf16", ptr(pl.dO[f]), ptr(pl.fpad_cl[f]), None, None, None, None,
+            self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), None, None, None, None,
                     ptr(pl.head_ws[f]), N, C, D, H, W, ncls, st)
         for i in range(last, 0, -1):
             sp = specs[i]
@@ -686,9 +710,10 @@ class Engine:
             pd, ph, pw = pl.dims[i - 1]
             s = sp["stride"][0]
             name = f"base.features.{i}"
-            if i == last and i not in pl.fpad_cl:
+            if i == last and i not in pl.feat_ids:
                 raise RuntimeError("the last backbone feature must feed a head")
-            self._bn_bwd_bf16(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N, sp["cout"], S, pl, st)
+            self._bn_bwd_bf16(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N, sp["cout"], S, pl, st, pre_np=pre_np)
+            pre_np = None
             out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
             self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs_bf16", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
                     ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, st)
@@ -697,18 +722,26 @@ class Engine:
             self._bn_bwd_bf16(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N, sp["cin"], S, pl, st)
             self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
                     ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, st)
-            accumulate = 1 if (i - 1) in pl.fpad_cl else 0  # the heads already wrote their share
-            self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bf16", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]), N,
-                    sp["cin"], pd, ph, pw, s, accumulate, st)
+            accumulate = 1 if (i - 1) in pl.feat_ids else 0  # the heads already wrote their share
+            Sp = pd * ph * pw
+            if s == 2 and pw % 4 == 0 and not self._bn_bwd_bf16_fused(N, Sp):
+                # big producer layer: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
+                pre_np = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, sp["cin"], pd, ph, pw)
+                self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_s2_patch_bf16", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight),
+                        ptr(pl.g_y[i - 1]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1]), ptr(pl.partials), N, sp["cin"], pd, ph, pw,
+                        accumulate, st)
+            else:
+                self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bf16", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
+                        N, sp["cin"], pd, ph, pw, s, accumulate, st)
         # stem: BatchNorm-backward sums, then the weight gradient with the BatchNorm backward applied on load
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
         D, H, W = pl.in_dims
-        L = _lib.load()
         vec = pl.bn_y[0]
-        NP = L.msl_bn_relu_bwd_bf16_num_partials(N, S0)
-        self._k("bn_bwd_reduce:stem", "msl_bn_relu_bwd_reduce_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec[0]), ptr(vec[1]),
-                ptr(vec[2]), ptr(vec[3]), ptr(pl.partials), N, specs[0]["cout"], S0, st)
+        NP = pre_np if pre_np is not None else L.msl_bn_relu_bwd_bf16_num_partials(N, S0)
+        if pre_np is None:
+            self._k("bn_bwd_reduce:stem", "msl_bn_relu_bwd_reduce_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec[0]), ptr(vec[1]),
+                    ptr(vec[2]), ptr(vec[3]), ptr(pl.partials), N, specs[0]["cout"], S0, st)
         _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(N * S0), ptr(gv["base.features.0.1.weight"]),
                   ptr(gv["base.features.0.1.bias"]), ptr(vec[4]), ptr(vec[5]), specs[0]["cout"], st)
         self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec), ptr(pl.saved_input),
@@ -942,11 +975,12 @@ class Engine:
             self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st, pre_np=pre_np)
             pre_np = None
             # dL/dy_i is final here: the pointwise weight gradient may start two or three chain kernels before dL/dz_i is
-            ev_dy = self._record(pl, f"dy{i}", st) if ms and self.early_pw_bww else None
+            rec_here = self.wgrad_record_at is None or i in self.wgrad_record_at or i == 1
+            ev_dy = self._record(pl, f"dy{i}", st) if ms and self.early_pw_bww and rec_here else None
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
                     sp["cout"], S, st)
             self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
-            ev_dz = self._record(pl, f"dz{i}", st) if ms else None
+            ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
             if accumulate and (i - 1) in side_feats:
                 self._wait(st, pl.events[f"head_done{i - 1}"])
@@ -963,7 +997,6 @@ class Engine:
                         ptr(vp[0]), ptr(vp[1]), ptr(vp[2]), ptr(vp[3]), ptr(pl.partials), ptr(pl.partials_wf), ptr(pl.w1_taps_t),
                         N, 32, pd, ph, pw, st)
                 pre_np = pl.fused_stem_np
-                ev_red = self._record(pl, "dz1_reduced", st) if ms else None
             elif np_red > 0 and 2 * sp["cin"] * np_red <= pl.partials.numel():
                 vp = pl.bn_y[i - 1]
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bnreduce", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight),
@@ -973,7 +1006,7 @@ class Engine:
             else:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
-            def wgrads(i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, ev_dz=ev_dz, fused_stem=fused_stem, ev_red=ev_red,
+            def wgrads(ev_dz, i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, fused_stem=fused_stem, ev_red=ev_red,
                        ev_dy=ev_dy):
                 # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there
                 streams = [stW, stH, stX]
@@ -999,14 +1032,21 @@ class Engine:
                 fn()
             pending = []
             if ms:
-                sinks.append((i, wgrads))
-                while sinks and sinks[0][0] >= i + self.wgrad_lag:
-                    sinks.pop(0)[1]()
+                sinks.append([i, wgrads, ev_dz])
+                if ev_dz is not None:  # blocks that did not record wait for the next record of the chain instead
+                    for ent in sinks:
+                        if ent[2] is None:
+                            ent[2] = ev_dz
+                while sinks and sinks[0][2] is not None and sinks[0][0] >= i + self.wgrad_lag:
+                    ent = sinks.pop(0)
+                    ent[1](ent[2])
             else:
-                wgrads()
+                wgrads(None)
             if wanted is not None and i in wanted:
-                for _, fn in sinks:
-                    fn()
+                if any(e is None for _, _, e in sinks):
+                    raise RuntimeError("MSL_WGRAD_RECORD_AT must contain every block that completes a gradient bucket")
+                for _, fn, e in sinks:
+                    fn(e)
                 sinks = []
             report(i, join_heads=self.split_wgrad > 0)
         # stem
@@ -1033,8 +1073,8 @@ class Engine:
                     None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         for fn in pending:
             fn()
-        for _, fn in sinks:
-            fn()
+        for _, fn, e in sinks:
+            fn(e)
         if ms:  # every gradient is complete once the side streams have been joined
             self._fork(pl, "bwd_join_w", stW, st)
             self._fork(pl, "bwd_join_h", stH, st)

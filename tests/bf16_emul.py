@@ -5,8 +5,9 @@ so there is no reference output to pin it to.  What can be pinned is that the HI
 design states - fp32 math on values that were rounded to bf16 at these points:
 
   forward   every raw convolution output y / z is stored as bf16 (its BatchNorm statistics come from the UNROUNDED
-            fp32 accumulators); the pointwise GEMM and the head convolutions take bf16 operands (activation rounded
-            after its fp32 affine + ReLU, weights rounded), the depthwise and stem convolutions fp32 operands;
+            fp32 accumulators); the pointwise GEMM takes bf16 operands (activation rounded after its fp32 affine + ReLU,
+            weights rounded), the depthwise and stem convolutions fp32 operands; the head convolutions fp32 operands in
+            the training step (fp32 kernels on an fp32 feature copy), bf16 operands in the inference path;
   backward  every activation gradient that goes to HBM (BatchNorm-backward outputs, conv bwd-data outputs, the head
             bwd-data output, their sums) is stored as bf16; weight gradients and all reductions are fp32 / fp64.
 
@@ -54,9 +55,11 @@ def _bn_bwd(g, yb, vec, gamma):
     return dy.float(), dgamma.float(), dbeta.float()
 
 
-def emulated_step(om, x, dlocs=None, dscores=None):
+def emulated_step(om, x, dlocs=None, dscores=None, f32_heads=True):
     """Forward (train mode, batch statistics) of the oracle model ``om`` under bf16 storage; with upstream gradients also
-    the backward.  Returns (locs, scores, grads) with grads keyed like ``om.named_parameters()`` (None without upstream)."""
+    the backward.  Returns (locs, scores, grads) with grads keyed like ``om.named_parameters()`` (None without upstream).
+    ``f32_heads``: the training step's head convolutions run on the fp32 kernels (fp32 feature copy, unrounded weights);
+    False: the bf16 head kernel of the inference path (bf16 feature copy and weights)."""
     feats = om.base.features
     nblk = len(feats)
     N = x.shape[0]
@@ -81,10 +84,11 @@ def emulated_step(om, x, dlocs=None, dscores=None):
     fmap, locs, scores = {}, [], []
     ncls = om.n_classes
     for k, f in enumerate(fids):
-        fmap[f] = bf(_act(yb[f], vy[f][0], vy[f][1]))                           # the bf16 channels-last copy
+        hr = (lambda t: t) if f32_heads else bf
+        fmap[f] = hr(_act(yb[f], vy[f][0], vy[f][1]))                           # the materialised feature copy
         lw, cw = P[f"pred_convs.loc_convs.{k}.weight"], P[f"pred_convs.cl_convs.{k}.weight"]
-        lo = F.conv3d(fmap[f], bf(lw), P[f"pred_convs.loc_convs.{k}.bias"], padding=1)
-        sc = F.conv3d(fmap[f], bf(cw), P[f"pred_convs.cl_convs.{k}.bias"], padding=1)
+        lo = F.conv3d(fmap[f], hr(lw), P[f"pred_convs.loc_convs.{k}.bias"], padding=1)
+        sc = F.conv3d(fmap[f], hr(cw), P[f"pred_convs.cl_convs.{k}.bias"], padding=1)
         locs.append(lo.permute(0, 2, 3, 4, 1).reshape(N, -1, 6))
         scores.append(sc.permute(0, 2, 3, 4, 1).reshape(N, -1, ncls))
     locs, scores = torch.cat(locs, 1), torch.cat(scores, 1)
@@ -101,7 +105,7 @@ def emulated_step(om, x, dlocs=None, dscores=None):
         dc = dscores[:, off:off + cnt].reshape(N, D, H, W, 2 * ncls).permute(0, 4, 1, 2, 3).contiguous()
         off += cnt
         lw, cw = P[f"pred_convs.loc_convs.{k}.weight"], P[f"pred_convs.cl_convs.{k}.weight"]
-        # bwd-data: fp32 dO x fp32 weights; weight gradient: fp32 dO x the bf16 feature copy
+        # bwd-data: fp32 dO x fp32 weights; weight gradient: fp32 dO x the feature copy
         gy[f] = bfg(torch.nn.grad.conv3d_input(fmap[f].shape, lw, dl, padding=1) + torch.nn.grad.conv3d_input(fmap[f].shape, cw, dc, padding=1))
         G[f"pred_convs.loc_convs.{k}.weight"] = torch.nn.grad.conv3d_weight(fmap[f], lw.shape, dl, padding=1)
         G[f"pred_convs.cl_convs.{k}.weight"] = torch.nn.grad.conv3d_weight(fmap[f], cw.shape, dc, padding=1)

@@ -41,7 +41,12 @@ def test_stem_fwd_bf16(cin, dims, stride):
 
 
 @pytest.mark.parametrize("N,C,dims,stride", [(1, 4, (10, 40, 40), 2), (2, 8, (9, 24, 24), 1), (1, 3, (7, 6, 6), 1),
-                                             (2, 16, (12, 12, 12), 2), (1, 2, (5, 7, 9), 2), (1, 2, (3, 96, 96), 2)])
+                                             (2, 16, (12, 12, 12), 2), (1, 2, (5, 7, 9), 2), (1, 2, (3, 96, 96), 2),
+                                             # square power-of-two planes: the register-marching wave kernels of the fp32
+                                             # path on bf16 storage (all seven layer shapes of a 128^3 input, ragged depths)
+                                             (1, 4, (64, 64, 64), 2), (2, 8, (32, 32, 32), 2), (2, 16, (16, 16, 16), 1),
+                                             (2, 16, (16, 16, 16), 2), (2, 32, (8, 8, 8), 1), (2, 32, (8, 8, 8), 2),
+                                             (2, 64, (4, 4, 4), 1), (1, 8, (5, 16, 16), 1), (1, 8, (7, 32, 32), 2)])
 @pytest.mark.parametrize("affine", [True, False])
 def test_dw_fwd_bf16(N, C, dims, stride, affine):
     L = _lib.load()
@@ -102,6 +107,11 @@ def test_materialize_and_head_fwd_bf16(N, C, dims):
     close(plain, act, 1e-6, 1e-6, "materialised activation (fp32 copy)")
     inner = pad[:, 1:-1, 1:-1, 1:-1, :].permute(0, 4, 1, 2, 3).float()
     close(inner, act, BF_EPS, 1e-6, "channels-last bf16 copy (rounded once, from the fp32 fma)")
+    pad32 = torch.zeros((N, C) + tuple(d + 2 for d in dims), device=DEV)  # what the training step's fp32 head kernels read
+    _lib.call("msl_bn_relu_materialize_bf16_pad32", ptr(K(yraw.to(torch.bfloat16))), ptr(K(sc)), ptr(K(sh)), ptr(pad32), N, C,
+              *dims, st())
+    close(pad32[:, :, 1:-1, 1:-1, 1:-1], act, 1e-6, 1e-6, "fp32 zero-haloed copy")
+    assert float(pad32.abs().sum() - pad32[:, :, 1:-1, 1:-1, 1:-1].abs().sum()) == 0.0, "halo must stay zero"
     a_b = inner.cpu()  # the head reference uses exactly what the kernel reads
     rl = F.conv3d(a_b.double(), bfr(lw).double(), lb.double(), padding=1).permute(0, 2, 3, 4, 1).reshape(N, -1, 6).float()
     rc = F.conv3d(a_b.double(), bfr(cw).double(), cb.double(), padding=1).permute(0, 2, 3, 4, 1).reshape(N, -1, ncls).float()
@@ -162,7 +172,11 @@ def test_pw_bwd_bf16(N, Cin, Cout, S):
 
 @pytest.mark.parametrize("N,C,dims,stride", [(1, 4, (10, 40, 40), 2), (2, 8, (9, 24, 24), 1), (1, 3, (7, 6, 6), 1),
                                              (2, 16, (12, 12, 12), 2), (1, 2, (5, 7, 9), 2), (2, 32, (16, 16, 16), 2),
-                                             (2, 64, (8, 8, 8), 1), (1, 2, (4, 128, 128), 2)])
+                                             (2, 64, (8, 8, 8), 1), (1, 2, (4, 128, 128), 2),
+                                             # wave kernels (flipped taps / weight gradient) and the stride-2 patch kernel
+                                             (1, 4, (64, 64, 64), 2), (2, 8, (32, 32, 32), 2), (2, 16, (16, 16, 16), 1),
+                                             (2, 64, (4, 4, 4), 1), (1, 8, (5, 16, 16), 1), (1, 8, (7, 32, 32), 2),
+                                             (1, 4, (6, 10, 12), 2)])
 def test_dw_bwd_bf16(N, C, dims, stride):
     L = _lib.load()
     x = bfr(rnd(N, C, *dims, seed=4))
@@ -185,7 +199,42 @@ def test_dw_bwd_bf16(N, C, dims, stride):
     close(part.sum(1).float().view(C, 1, 3, 3, 3), w.grad, 1e-4, 1e-4, "dw bwd weight bf16")
 
 
-@pytest.mark.parametrize("N,C,S", [(3, 8, 192), (2, 64, 4096), (4, 32, 32768), (1, 16, 100), (2, 512, 64)])
+@pytest.mark.parametrize("N,C,dims", [(2, 8, (16, 16, 16)), (1, 4, (32, 32, 32)), (2, 4, (6, 10, 12))])
+def test_dw_s2_bwd_data_with_bn_reduce_bf16(N, C, dims):
+    """Stride-2 bwd-data that also emits the BatchNorm-backward sums of the layer it writes, from the ROUNDED gradient
+    (what the apply pass reads back), with and without accumulation into an existing gradient."""
+    L = _lib.load()
+    y = bfr(rnd(N, C, *dims, seed=4) * 2 + 0.5).requires_grad_(True)
+    gamma, beta = (rnd(C, seed=21).abs() + 0.5).requires_grad_(True), rnd(C, seed=22, scale=0.2).requires_grad_(True)
+    w = rnd(C, 1, 3, 3, 3, seed=5, scale=0.4)
+    a = torch.relu(F.batch_norm(y, None, None, gamma, beta, True, 0.1, 1e-5))
+    out = F.conv3d(a, w, stride=2, padding=1, groups=C)
+    dz = bfr(rnd(*out.shape, seed=8))
+    base = bfr(rnd(*y.shape, seed=9))
+    ga = bfr(base + torch.nn.grad.conv3d_input(a.shape, w, dz, stride=2, padding=1, groups=C))  # stored gradient
+    a.backward(ga)
+    S = dims[0] * dims[1] * dims[2]
+    yd = y.detach().double()
+    part = torch.stack([yd.sum((0, 2, 3, 4)), (yd ** 2).sum((0, 2, 3, 4))]).view(2, C, 1).contiguous().to(DEV)
+    vec = torch.zeros((8, C), device=DEV)
+    _lib.call("msl_bn_finalize", ptr(part), 1, float(N * S), ptr(K(gamma.detach())), ptr(K(beta.detach())), None, None, None, 0.1,
+              1e-5, ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C, st())
+    NP = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, C, *dims)
+    bp = torch.full((2 * C * NP,), float("nan"), dtype=torch.float64, device=DEV)
+    g = b16(base)
+    _lib.call("msl_dwconv_bwd_data_s2_patch_bf16", ptr(b16(dz)), ptr(K(w)), ptr(g), ptr(b16(y.detach())), ptr(vec), ptr(bp), N, C,
+              *dims, 1, st())
+    close(g.float(), ga, 2 * BF_EPS, 1e-5, "dw s2 bwd data (accumulate) bf16")
+    dgam, dbet = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+    _lib.call("msl_bn_bwd_finalize", ptr(bp), NP, float(N * S), ptr(dgam), ptr(dbet), ptr(vec[4]), ptr(vec[5]), C, st())
+    # one gradient element tipped to the neighbouring bf16 value moves a sum by 2^-8 of that element
+    tol = 4 * BF_EPS * float(ga.abs().max())
+    close(dgam, gamma.grad, 1e-3, tol, "dgamma from the fused reduce")
+    close(dbet, beta.grad, 1e-3, tol, "dbeta from the fused reduce")
+
+
+@pytest.mark.parametrize("N,C,S", [(3, 8, 192), (2, 64, 4096), (4, 32, 32768), (1, 16, 100), (2, 512, 64), (4, 16, 8192),
+                                   (2, 8, 16384), (4, 128, 4096), (1, 8, 24)])
 def test_bn_relu_bwd_bf16(N, C, S):
     L = _lib.load()
     y = bfr(rnd(N, C, S, seed=20) * 2 + 1).requires_grad_(True)
@@ -211,7 +260,7 @@ def test_bn_relu_bwd_bf16(N, C, S):
     close(dbet, beta.grad, 1e-4, 1e-4, "dbeta")
     atol = 2 * BF_EPS * float(y.grad.abs().max())  # the result is a difference of terms rounded once at the end
     close(out.float(), y.grad, 2 * BF_EPS, atol, "bn bwd dy bf16")
-    if N * S <= 65536:
+    if N * S <= 65536:  # <= 32768 with S % 8 == 0: the register-resident kernel
         g2 = gd.clone()
         dg2, db2 = torch.empty(C, device=DEV), torch.empty(C, device=DEV)
         _lib.call("msl_bn_relu_bwd_fused_bf16", ptr(g2), ptr(yd16), ptr(vec), ptr(dg2), ptr(db2), ptr(g2), N, C, S, st())
