@@ -605,6 +605,8 @@ class Engine:
         pl.generation += 1
         pl.saved_input, pl.trained_mode = x, training
         st = self._stream()
+        ms = self.multi_stream and need_grad  # heads of the earlier scales beside the backbone (training step)
+        stH = self.side_streams(x.device)[0].cuda_stream if ms else st
         N = pl.N
         ncls = m.n_classes
         _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
@@ -641,7 +643,11 @@ class Engine:
                         ptr(pl.bn_y[i][1]), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
                 if want_features:
                     out_feats[i] = pl.fpad[i][:, :, 1:-1, 1:-1, 1:-1].clone()
-                self._head_forward(pl, i, st)
+                if ms and i != len(specs) - 1:  # beside the next blocks, on the heads stream
+                    self._fork(pl, f"fwd_feat{i}", st, stH)
+                    self._head_forward(pl, i, stH)
+                else:
+                    self._head_forward(pl, i, st)
             elif i in pl.feat_ids:
                 plain = None
                 if want_features:
@@ -654,6 +660,8 @@ class Engine:
                         ncls, st)
                 self._k(f"head_fwd{i}", "msl_head_conv_fwd_bf16", ptr(pl.fpad_cl[i]), ptr(pl.Wp[i]), ptr(lc.bias), ptr(cc.bias),
                         ptr(pl.locs), ptr(pl.scores), N, sp["cout"], D, H, W, pl.P, pl.prior_off[i], ncls, st)
+        if ms:
+            self._fork(pl, "fwd_heads_done", stH, st)
         if nan_check:
             _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
             _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
@@ -685,24 +693,46 @@ class Engine:
 
     def _backward_bf16(self, pl, dlocs, dscores, on_bucket_ready=None):
         """Backward of the bf16 training step: activation gradients are bf16 tensors, weight gradients fp32 partial sums
-        folded by the batched reduction; one stream, and a data-parallel reducer gets all its buckets at the end."""
+        folded by the batched reduction.  Same three-stream schedule as the fp32 step (dependency chain on the main stream,
+        head gradients of the earlier scales on the heads stream, weight gradients alternating over the two side streams);
+        a data-parallel reducer gets all its buckets at the end."""
         m, specs, feats = self.model, self.layer_specs, self.model.base.features
         gv = self.arena.grad_views
         st = self._stream()
+        ms = self.multi_stream
+        if ms:
+            sH, sW = self.side_streams(pl.locs.device)
+            stH, stW = sH.cuda_stream, sW.cuda_stream
+        else:
+            stH = stW = st
         N, ncls = pl.N, m.n_classes
         dlocs, dscores = dlocs.contiguous(), dscores.contiguous()
         last = len(specs) - 1
         L = _lib.load()
         pre_np = None
-        for k, f in enumerate(pl.feat_ids):
+        if last not in pl.feat_ids:
+            raise RuntimeError("the last backbone feature must feed a head")
+
+        def head(f, s_data, s_weight, done=None):
             C = specs[f]["cout"]
             D, H, W = pl.dims[f]
             self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P,
-                    pl.prior_off[f], ncls, st)
+                    pl.prior_off[f], ncls, s_data)
             self._k(f"head_bwd{f}", "msl_head_conv_bwd_data_bf16", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W,
-                    ncls, st)
+                    ncls, s_data)
+            if done is not None:
+                self._record(pl, done, s_data)
+            if s_weight != s_data:
+                self._wait(s_weight, self._record(pl, f"head_dO{f}", s_data))
             self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), None, None, None, None,
-                    ptr(pl.head_ws[f]), N, C, D, H, W, ncls, st)
+                    ptr(pl.head_ws[f]), N, C, D, H, W, ncls, s_weight)
+
+        side_feats = [f for f in pl.feat_ids if f != last] if ms else []
+        if side_feats:
+            self._fork(pl, "bwd_loss_ready", st, stH)
+        head(last, st, stW)  # its data gradient starts the chain
+        for f in reversed(side_feats) if ms else [f for f in pl.feat_ids if f != last]:
+            head(f, stH, stH, done=f"head_done{f}" if ms else None)
         for i in range(last, 0, -1):
             sp = specs[i]
             D, H, W = pl.dims[i]
@@ -710,19 +740,18 @@ class Engine:
             pd, ph, pw = pl.dims[i - 1]
             s = sp["stride"][0]
             name = f"base.features.{i}"
-            if i == last and i not in pl.feat_ids:
-                raise RuntimeError("the last backbone feature must feed a head")
             self._bn_bwd_bf16(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N, sp["cout"], S, pl, st, pre_np=pre_np)
             pre_np = None
-            out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
-            self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs_bf16", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
-                    ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, st)
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data_bf16", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N,
                     sp["cin"], sp["cout"], S, st)
             self._bn_bwd_bf16(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N, sp["cin"], S, pl, st)
-            self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
-                    ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, st)
+            sX = st
+            if ms:  # both weight gradients of the block on a side stream, once dL/dy_i and dL/dz_i are final
+                sX = stW if i % 2 else stH
+                self._wait(sX, self._record(pl, f"dz{i}", st))
             accumulate = 1 if (i - 1) in pl.feat_ids else 0  # the heads already wrote their share
+            if accumulate and (i - 1) in side_feats:
+                self._wait(st, pl.events[f"head_done{i - 1}"])
             Sp = pd * ph * pw
             if s == 2 and pw % 4 == 0 and not self._bn_bwd_bf16_fused(N, Sp):
                 # big producer layer: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
@@ -733,6 +762,11 @@ class Engine:
             else:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bf16", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
+            out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
+            self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs_bf16", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
+                    ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, sX)
+            self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
+                    ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, sX)
         # stem: BatchNorm-backward sums, then the weight gradient with the BatchNorm backward applied on load
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
@@ -746,6 +780,9 @@ class Engine:
                   ptr(gv["base.features.0.1.bias"]), ptr(vec[4]), ptr(vec[5]), specs[0]["cout"], st)
         self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec), ptr(pl.saved_input),
                 None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        if ms:  # every gradient is complete once the side streams have been joined
+            self._fork(pl, "bwd_join_w", stW, st)
+            self._fork(pl, "bwd_join_h", stH, st)
         self._grad_reduce(pl, "all", None, st)
         if on_bucket_ready is not None:
             for stage in ["heads"] + list(range(last, -1, -1)):
