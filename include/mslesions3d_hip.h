@@ -188,12 +188,19 @@ int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* 
  * BatchNorm-backward partials [2][C][NP] of the layer written, NP = msl_dwconv_bwd_data_bnreduce_num_partials */
 int msl_dwconv_bwd_data_s2_patch_bf16(const void* dy, const float* w, void* g_in, const void* y_prev, const float* bn_vec,
                                       double* partials, int N, int C, int D, int H, int W, int accumulate, void* stream);
+int msl_dwconv_fwd_wave_bf16_fold(const void* x, const double* in_partials, int in_np, double in_count, const float* gamma,
+                                  const float* beta, float eps, const float* w, void* y, double* partials, int N, int C, int D,
+                                  int H, int W, int stride, void* stream);
 int msl_dwconv_bwd_weight_wave_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift,
                                     double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
 int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                         double* partials, int N, int C, int D, int H, int W, int stride, void* stream);
 int msl_pwconv_fwd_bf16_num_partials(int N, int S);
 /* pointwise GEMM on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) */
+/* input BatchNorm folded from the producer's partials (in_np <= 64, Cin <= 1024; MSL_ERR_UNSUPPORTED otherwise) */
+int msl_pwconv_fwd_bf16_fold(const void* z, const double* in_partials, int in_np, double in_count, const float* gamma,
+                             const float* beta, float eps, const float* w, void* y, double* partials, int N, int Cin, int Cout,
+                             int S, void* stream);
 int msl_pwconv_fwd_bf16(const void* z, const float* in_scale, const float* in_shift, const float* w, void* y,
                         double* partials, int N, int Cin, int Cout, int S, void* stream);
 /* relu(bn(y)) of a head feature map -> bf16 CHANNELS-LAST zero-haloed copy (N,D+2,H+2,W+2,C), halo zeroed by the caller */

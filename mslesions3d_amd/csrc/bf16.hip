@@ -125,21 +125,33 @@ __global__ __launch_bounds__(256) void dw_fwd_bf16_kernel(const u16* __restrict_
 // Y_n[M x S] = W[M x K] . act(Z_n)[K x S].  Workgroup tile 64 (rows) x 64 (columns); K in chunks of 32; both operands go
 // through LDS as bf16 with k contiguous (the MFMA wants 8 consecutive k per lane; NCDHW has k strided by S, so the
 // activation chunk is transposed on its way into LDS).  4 waves = 2 x 2 tiles of 32 x 32.
-constexpr int PB_BM = 64, PB_BN = 64, PB_BK = 32, PB_LD = PB_BK + 8;  // 80-byte rows: 16-byte aligned fragments
+constexpr int PB_BM = 64, PB_BN = 64, PB_BK = 32, PB_LD = PB_BK + 8, PB_MAXK = 1024;  // 80-byte rows: 16-byte aligned fragments
 
 // TRANS_W: weight element (m, k) = Wt[k * M + m] (bwd-data: M = Cin, K = Cout, the same weights read transposed).
 template <bool STATS, bool TRANS_W = false>
 __global__ __launch_bounds__(256) void pw_fwd_bf16_kernel(const u16* __restrict__ Z, const float* __restrict__ in_scale,
                                                           const float* __restrict__ in_shift, const float* __restrict__ Wt,
                                                           u16* __restrict__ Y, double* __restrict__ partials, int M, int K,
-                                                          int S) {
+                                                          int S, msl::BnFold fold) {
   __shared__ __align__(16) u16 Ws[PB_BM * PB_LD];
   __shared__ __align__(16) u16 Xs[PB_BN * PB_LD];
+  __shared__ float fsc[PB_MAXK], fsh[PB_MAXK];  // input BatchNorm folded from its producer's partials (fold.partials)
+  if (fold.partials) {  // K <= PB_MAXK, fold.NP <= 64 (host-checked): one thread per channel, the finalize kernel's order
+    for (int c = threadIdx.x; c < K; c += 256) {
+      float a, b, m_, i_;
+      double v_;
+      msl::bn_fold_serial(fold, c, a, b, m_, i_, v_);
+      fsc[c] = a;
+      fsh[c] = b;
+    }
+    __syncthreads();
+  }
   const int n = blockIdx.z, m0 = blockIdx.y * PB_BM, s0 = blockIdx.x * PB_BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int r = lane & 31, h = lane >> 5;
   const u16* Zn = Z + (size_t)n * K * S;
-  const bool affine = in_scale != nullptr;
+  const bool folded = fold.partials != nullptr;
+  const bool affine = in_scale != nullptr || folded;
   const bool vec_ok = (S & 7) == 0;
   // staging roles
   const int wrow = tid >> 2, wk8 = (tid & 3) * 8;   // weight chunk: row, 8 consecutive k
@@ -171,7 +183,7 @@ __global__ __launch_bounds__(256) void pw_fwd_bf16_kernel(const u16* __restrict_
         for (int i = 0; i < 8; ++i) xv8[i] = col + i < S ? msl::bf2f(zp[col + i]) : 0.f;
       }
       if (affine) {
-        const float sc = in_scale[k0 + xk], sh = in_shift[k0 + xk];
+        const float sc = folded ? fsc[k0 + xk] : in_scale[k0 + xk], sh = folded ? fsh[k0 + xk] : in_shift[k0 + xk];
 #pragma unroll
         for (int i = 0; i < 8; ++i) xv8[i] = (s0 + xc8 + i < S) ? msl::act(xv8[i], sc, sh) : 0.f;
       }
@@ -670,19 +682,37 @@ int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_sh
 int msl_pwconv_fwd_bf16_num_partials(int N, int S) { return N * msl::cdiv(S, PB_BN) * 2; }
 
 // z (N,Cin,S) bf16 raw + optional input affine -> y (N,Cout,S) bf16 raw (+ stat partials [2][Cout][NP] or NULL)
-int msl_pwconv_fwd_bf16(const void* z, const float* in_scale, const float* in_shift, const float* w, void* y,
-                        double* partials, int N, int Cin, int Cout, int S, void* stream) {
+static const msl::BnFold pb_nofold{nullptr, 0, 0, 1.0, nullptr, nullptr, 0.f};
+
+static int pw_fwd_bf16_impl(const void* z, const float* in_scale, const float* in_shift, const msl::BnFold& fold, const float* w,
+                            void* y, double* partials, int N, int Cin, int Cout, int S, void* stream) {
   if (N <= 0 || S <= 0 || Cin % PB_BK != 0 || Cout <= 0) return MSL_ERR_ARG;
   dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cout, PB_BM), N);
   hipStream_t st = (hipStream_t)stream;
   if (partials)
     hipLaunchKernelGGL(pw_fwd_bf16_kernel<true>, grid, dim3(256), 0, st, (const u16*)z, in_scale, in_shift, w, (u16*)y,
-                       partials, Cout, Cin, S);
+                       partials, Cout, Cin, S, fold);
   else
     hipLaunchKernelGGL(pw_fwd_bf16_kernel<false>, grid, dim3(256), 0, st, (const u16*)z, in_scale, in_shift, w, (u16*)y,
-                       partials, Cout, Cin, S);
+                       partials, Cout, Cin, S, fold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
+}
+
+int msl_pwconv_fwd_bf16(const void* z, const float* in_scale, const float* in_shift, const float* w, void* y,
+                        double* partials, int N, int Cin, int Cout, int S, void* stream) {
+  return pw_fwd_bf16_impl(z, in_scale, in_shift, pb_nofold, w, y, partials, N, Cin, Cout, S, stream);
+}
+
+// ... with the input BatchNorm folded from its producer's statistics partials [2][Cin][in_np] (in_np <= 64, Cin <= 1024: every
+// workgroup rebuilds the Cin (scale, shift) pairs in its prologue, in the finalize kernel's summation order -> the same bits)
+int msl_pwconv_fwd_bf16_fold(const void* z, const double* in_partials, int in_np, double in_count, const float* gamma,
+                             const float* beta, float eps, const float* w, void* y, double* partials, int N, int Cin, int Cout,
+                             int S, void* stream) {
+  if (!in_partials || in_np <= 0) return MSL_ERR_ARG;
+  if (in_np > 64 || Cin > PB_MAXK) return MSL_ERR_UNSUPPORTED;
+  const msl::BnFold fold{in_partials, in_np, Cin, in_count, gamma, beta, eps};
+  return pw_fwd_bf16_impl(z, nullptr, nullptr, fold, w, y, partials, N, Cin, Cout, S, stream);
 }
 
 // y (N,C,D,H,W) bf16 raw + affine -> pad_cl (N,D+2,H+2,W+2,C) bf16 (halo pre-zeroed by the caller) [+ plain fp32 NCDHW]
@@ -713,7 +743,7 @@ int msl_pwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, 
   if (N <= 0 || S <= 0 || Cout % PB_BK != 0 || Cin % 8 != 0) return MSL_ERR_ARG;
   dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cin, PB_BM), N);
   hipLaunchKernelGGL((pw_fwd_bf16_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, nullptr, nullptr,
-                     w, (u16*)g_in, nullptr, Cin, Cout, S);
+                     w, (u16*)g_in, nullptr, Cin, Cout, S, pb_nofold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -1475,6 +1475,25 @@ int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* 
   return MSL_OK;
 }
 
+// ... with the input BatchNorm folded from its producer's statistics partials [2][C][in_np] (same arithmetic and summation
+// order as msl_bn_finalize -> the same bits), so that no finalize launch sits between producer and consumer
+int msl_dwconv_fwd_wave_bf16_fold(const void* x, const double* in_partials, int in_np, double in_count, const float* gamma,
+                                  const float* beta, float eps, const float* w, void* y, double* partials, int N, int C, int D,
+                                  int H, int W, int stride, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2) || !in_partials || in_np <= 0) return MSL_ERR_ARG;
+  const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+  if (!wp.ok) return MSL_ERR_UNSUPPORTED;
+  const msl::BnFold fold{in_partials, in_np, C, in_count, gamma, beta, eps};
+  if (stride == 1)
+    launch_wave(wp, reinterpret_cast<const dwu16*>(x), (const float*)nullptr, (const float*)nullptr, w, reinterpret_cast<dwu16*>(y),
+                partials, N, C, D, 0, 0, fold, (hipStream_t)stream);
+  else
+    launch_wave_s2(wp, reinterpret_cast<const dwu16*>(x), (const float*)nullptr, (const float*)nullptr, w,
+                   reinterpret_cast<dwu16*>(y), partials, N, C, D, fold, (hipStream_t)stream);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
 // dz (N,C,OD,OH,OW), x (N,C,D,H,W) bf16 (+ input affine) -> fp64 partials [C*27][NP], NP = msl_dwconv_wave_num_partials
 int msl_dwconv_bwd_weight_wave_bf16(const void* dz, const void* x, const float* in_scale, const float* in_shift,
                                     double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {

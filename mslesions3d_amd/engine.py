@@ -236,6 +236,7 @@ class Engine:
         self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
         self.extra = {}
         self.early_pw_bww = os.environ.get("MSL_EARLY_PW_BWW", "0") == "1"
+        self.fold_bf16 = os.environ.get("MSL_BF16_FOLD", "1") == "1"  # bf16 step: BatchNorm finalize folded into consumers
         # an event record costs the chain ~6 us (the next kernel waits for the barrier packet): the weight gradients of
         # several blocks can share one record, at the price of starting up to that many blocks later
         e = os.environ.get("MSL_WGRAD_RECORD_AT")
@@ -618,25 +619,46 @@ class Engine:
         if need_grad:  # fp32 fragment copies for the head bwd-data kernel
             self._pack_head_weights(pl, st)
         part = (lambda t: ptr(t)) if training else (lambda t: None)
+        L = _lib.load()
+        later = []  # BatchNorms folded into their consumer: running statistics + backward vectors in ONE launch at the end
         D, H, W = pl.in_dims
         self._k("stem_fwd", "msl_stem_conv_fwd_bf16", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), part(pl.part_y[0]), N,
                 specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
         od, oh, ow = pl.dims[0]
-        if training:
-            self._bn_fwd(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], N * od * oh * ow, True, st)
         out_feats = {}
         for i in range(1, len(specs)):
             sp, blk = specs[i], feats[i]
             pd, ph, pw = pl.dims[i - 1]
             D, H, W = pl.dims[i]
             S = D * H * W
-            self._k(f"dw_fwd{i}", "msl_dwconv_fwd_bf16", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
-                    ptr(blk.conv1.weight), ptr(pl.z[i]), part(pl.part_z[i]), N, sp["cin"], pd, ph, pw, sp["stride"][0], st)
-            if training:
-                self._bn_fwd(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, True, st)
-            self._k(f"pw_fwd{i}", "msl_pwconv_fwd_bf16", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
-                    ptr(blk.conv2.weight), ptr(pl.y[i]), part(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
-            if training:
+            bn_prev = feats[0][1] if i == 1 else feats[i - 1].bn2
+            cnt_prev = N * pd * ph * pw
+            # the consumer rebuilds (scale, shift) from the producer's partials when they are few (<= 64: every wave /
+            # workgroup repeats the sum) - no finalize launch between the two; feature maps need the vectors anyway
+            fold_y = (training and self.fold_bf16 and pl.np_y[i - 1] <= 64 and (i - 1) not in pl.feat_ids
+                      and L.msl_dwconv_wave_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]) > 0)
+            if training and not fold_y and (i - 1) not in pl.feat_ids:  # (a feature map's vectors exist already)
+                self._bn_fwd(bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev, True, st)
+            if fold_y:
+                later.append((bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev))
+                self._k(f"dw_fwd{i}", "msl_dwconv_fwd_wave_bf16_fold", ptr(pl.y[i - 1]), ptr(pl.part_y[i - 1]), pl.np_y[i - 1],
+                        float(cnt_prev), ptr(bn_prev.weight), ptr(bn_prev.bias), bn_prev.eps, ptr(blk.conv1.weight), ptr(pl.z[i]),
+                        ptr(pl.part_z[i]), N, sp["cin"], pd, ph, pw, sp["stride"][0], st)
+            else:
+                self._k(f"dw_fwd{i}", "msl_dwconv_fwd_bf16", ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]), ptr(pl.bn_y[i - 1][1]),
+                        ptr(blk.conv1.weight), ptr(pl.z[i]), part(pl.part_z[i]), N, sp["cin"], pd, ph, pw, sp["stride"][0], st)
+            fold_z = training and self.fold_bf16 and pl.np_z[i] <= 64 and sp["cin"] <= 1024
+            if fold_z:
+                later.append((blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S))
+                self._k(f"pw_fwd{i}", "msl_pwconv_fwd_bf16_fold", ptr(pl.z[i]), ptr(pl.part_z[i]), pl.np_z[i], float(N * S),
+                        ptr(blk.bn1.weight), ptr(blk.bn1.bias), blk.bn1.eps, ptr(blk.conv2.weight), ptr(pl.y[i]),
+                        ptr(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
+            else:
+                if training:
+                    self._bn_fwd(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, True, st)
+                self._k(f"pw_fwd{i}", "msl_pwconv_fwd_bf16", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
+                        ptr(blk.conv2.weight), ptr(pl.y[i]), part(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
+            if training and i in pl.feat_ids:  # the materialisation below reads the vectors
                 self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
             if i in pl.feat_ids and need_grad:
                 self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16_pad32", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
@@ -660,6 +682,8 @@ class Engine:
                         ncls, st)
                 self._k(f"head_fwd{i}", "msl_head_conv_fwd_bf16", ptr(pl.fpad_cl[i]), ptr(pl.Wp[i]), ptr(lc.bias), ptr(cc.bias),
                         ptr(pl.locs), ptr(pl.scores), N, sp["cout"], D, H, W, pl.P, pl.prior_off[i], ncls, st)
+        if training and later:
+            self._finalize_all(pl, later, st)
         if ms:
             self._fork(pl, "fwd_heads_done", stH, st)
         if nan_check:

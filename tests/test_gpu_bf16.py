@@ -128,6 +128,51 @@ def test_materialize_and_head_fwd_bf16(N, C, dims):
     assert bool((locs[:, :off] == 7).all()) and bool((locs[:, off + 2 * S:] == 7).all())
 
 
+@pytest.mark.parametrize("NP", [1, 8, 64])
+def test_bf16_bn_fold_is_bit_identical_to_the_explicit_finalize(NP):
+    """The consumers that rebuild (scale, shift) from their producer's statistics partials (no finalize launch in between)
+    must produce the bits of the explicit msl_bn_finalize + vector path."""
+    L = _lib.load()
+    N, C, Cout, dims = 2, 64, 128, (8, 8, 8)
+    S = dims[0] * dims[1] * dims[2]
+    x = bfr(rnd(N, C, *dims, seed=4) * 1.5 + 0.3)
+    g = torch.Generator().manual_seed(7)
+    # consistent partials: split the true sums unevenly over NP slots
+    xd = x.double()
+    wgt = torch.rand(NP, generator=g, dtype=torch.float64) + 0.1
+    wgt /= wgt.sum()
+    part = torch.stack([xd.sum((0, 2, 3, 4))[:, None] * wgt, (xd ** 2).sum((0, 2, 3, 4))[:, None] * wgt]).contiguous().to(DEV)
+    gamma, beta = rnd(C, seed=21).abs() + 0.5, rnd(C, seed=22, scale=0.2)
+    vec = torch.zeros((8, C), device=DEV)
+    _lib.call("msl_bn_finalize", ptr(part), NP, float(N * S), ptr(K(gamma)), ptr(K(beta)), None, None, None, 0.1, 1e-5,
+              ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), C, st())
+    xb = b16(x)
+    # depthwise (wave kernels), stride 1 and 2
+    for stride in (1, 2):
+        w = rnd(C, 1, 3, 3, 3, seed=5, scale=0.4)
+        od = tuple((d - 1) // stride + 1 for d in dims)
+        ya = torch.full((N, C) + od, float("nan"), dtype=torch.bfloat16, device=DEV)
+        yb = torch.full((N, C) + od, float("nan"), dtype=torch.bfloat16, device=DEV)
+        npo = L.msl_dwconv_fwd_bf16_num_partials(N, C, *dims, stride)
+        pa = torch.zeros(2 * C * npo, dtype=torch.float64, device=DEV)
+        pb = torch.zeros(2 * C * npo, dtype=torch.float64, device=DEV)
+        _lib.call("msl_dwconv_fwd_bf16", ptr(xb), ptr(vec[0]), ptr(vec[1]), ptr(K(w)), ptr(ya), ptr(pa), N, C, *dims, stride, st())
+        _lib.call("msl_dwconv_fwd_wave_bf16_fold", ptr(xb), ptr(part), NP, float(N * S), ptr(K(gamma)), ptr(K(beta)), 1e-5,
+                  ptr(K(w)), ptr(yb), ptr(pb), N, C, *dims, stride, st())
+        assert torch.equal(ya, yb) and torch.equal(pa, pb), f"depthwise stride {stride}"
+    # pointwise
+    w2 = rnd(Cout, C, seed=11) / C ** 0.5
+    ya = torch.full((N, Cout, S), float("nan"), dtype=torch.bfloat16, device=DEV)
+    yb = torch.full((N, Cout, S), float("nan"), dtype=torch.bfloat16, device=DEV)
+    npo = L.msl_pwconv_fwd_bf16_num_partials(N, S)
+    pa = torch.zeros(2 * Cout * npo, dtype=torch.float64, device=DEV)
+    pb = torch.zeros(2 * Cout * npo, dtype=torch.float64, device=DEV)
+    _lib.call("msl_pwconv_fwd_bf16", ptr(xb), ptr(vec[0]), ptr(vec[1]), ptr(K(w2)), ptr(ya), ptr(pa), N, C, Cout, S, st())
+    _lib.call("msl_pwconv_fwd_bf16_fold", ptr(xb), ptr(part), NP, float(N * S), ptr(K(gamma)), ptr(K(beta)), 1e-5, ptr(K(w2)),
+              ptr(yb), ptr(pb), N, C, Cout, S, st())
+    assert torch.equal(ya, yb) and torch.equal(pa, pb), "pointwise"
+
+
 # ------------------------------------------------------------------------------------ backward kernels (configs[2])
 def b16(t):
     return K(t.detach().to(torch.bfloat16))  # kept alive until the end of the test (see K)
