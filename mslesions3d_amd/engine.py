@@ -230,7 +230,6 @@ class Engine:
         # finalize launches from the forward chain, but every workgroup then re-reads the partials: measured on
         # MI355X it costs each consumer what the launch saved (depthwise block 1: 40 -> 49 us) — off by default.
         self.fold_bn = False     # fold EVERY BatchNorm into its consumers (slower: big layers have thousands of partials)
-        # default: fold only the BatchNorms with at most this many partials per channel (tuning knob: MSL_FOLD_NP_MAX)
         # 0: every block's weight gradients on the wgrad stream; 1: odd blocks on the heads stream (idle once the head
         # gradients are done); 2: three ways, the third on a stream of its own
         self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
@@ -246,7 +245,11 @@ class Engine:
         self.wgrad_lag = int(os.environ.get("MSL_WGRAD_LAG", "1"))
         e = os.environ.get("MSL_WGRAD_ON_HEADS")
         self.wgrad_on_heads = None if e is None else {int(v) for v in e.split(",") if v.strip()}
-        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "65536"))
+        # default: fold only the BatchNorms with at most this many partials per channel (MSL_FOLD_NP_MAX).  Round 2 A/B at
+        # 128^3 x 4 (tools/probes/r02_fold.sh): thresholds 32 / 64 / 512 / 65536 give the same step time (0.928-0.935 ms) but
+        # the depthwise forwards take 56 / 60 / 65 / 69 us back to back - a folded stem BatchNorm (1024 partials) costs block
+        # 1's depthwise 4.5 us, what the finalize launch it saves costs the chain.  64 keeps the kernels near their roofline.
+        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "64"))
         self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", "32"))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
         self.side = {}
