@@ -320,12 +320,6 @@ int msl_event_elapsed_ms(void* start, void* stop, float* out_ms);
 int msl_event_destroy(void* ev);
 int msl_event_record(void* ev, void* stream);
 int msl_stream_wait_event(void* stream, void* ev);
-/* capture everything enqueued on `stream` (and on streams forked from it) between begin and end into an executable
- * HIP graph; relaunch it with msl_graph_launch */
-int msl_graph_begin(void* stream);
-int msl_graph_end(void* stream, void** exec_out);
-int msl_graph_launch(void* exec, void* stream);
-int msl_graph_destroy(void* exec);
 /* native replay of a recorded launch sequence (generated trampolines, csrc/gen_runner.py): fn_ids from
  * msl_program_fn_id(); slots = n x stride raw 64-bit argument values; *failed_at = index of the failing call */
 int msl_program_fn_id(const char* name);

@@ -118,10 +118,6 @@ _SIGNATURES = {
     "msl_run_program": (_I, [_P, _P, _I, _I, _P]),
     "msl_run_program_mt": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
-    "msl_graph_begin": (_I, [_P]),
-    "msl_graph_end": (_I, [_P, _P]),
-    "msl_graph_launch": (_I, [_P, _P]),
-    "msl_graph_destroy": (_I, [_P]),
     "msl_event_create": (_I, [_P]),
     "msl_event_create_timed": (_I, [_P]),
     "msl_event_elapsed_ms": (_I, [_P, _P, _P]),

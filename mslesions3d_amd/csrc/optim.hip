@@ -258,22 +258,6 @@ int msl_stream_wait_event(void* stream, void* ev) {
   return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
 }
 
-// ---- HIP graph capture of a launch sequence (single-GPU training step) ------------------------------------------
-int msl_graph_begin(void* stream) { return (int)hipStreamBeginCapture((hipStream_t)stream, hipStreamCaptureModeRelaxed); }
-int msl_graph_end(void* stream, void** exec_out) {
-  hipGraph_t graph = nullptr;
-  hipError_t e = hipStreamEndCapture((hipStream_t)stream, &graph);
-  if (e != hipSuccess) return (int)e;
-  hipGraphExec_t exec = nullptr;
-  e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  (void)hipGraphDestroy(graph);
-  if (e != hipSuccess) return (int)e;
-  *exec_out = (void*)exec;
-  return MSL_OK;
-}
-int msl_graph_launch(void* exec, void* stream) { return (int)hipGraphLaunch((hipGraphExec_t)exec, (hipStream_t)stream); }
-int msl_graph_destroy(void* exec) { return (int)hipGraphExecDestroy((hipGraphExec_t)exec); }
-
 int msl_abi_version(void) { return 1; }
 
 }  // extern "C"

@@ -685,7 +685,8 @@ constexpr int STEM_BW_BLOCKS = 512;
 extern "C" {
 
 static inline int stem_fwd_blocks(int OD, int OH, int OW) {
-  return std::min(STEM_FWD_BLOCKS_PER_IMAGE, msl::cdiv(OD * OH * msl::cdiv(OW, 64), 4));
+  static const int per_image = getenv("MSL_STEM_FWD_BLOCKS") ? atoi(getenv("MSL_STEM_FWD_BLOCKS")) : STEM_FWD_BLOCKS_PER_IMAGE;
+  return std::min(per_image, msl::cdiv(OD * OH * msl::cdiv(OW, 64), 4));
 }
 
 int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW) { return N * stem_fwd_blocks(OD, OH, OW); }
