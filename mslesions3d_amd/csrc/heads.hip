@@ -926,7 +926,8 @@ inline HwPlan head_bw_plan(int N, int C, int D, int H, int W, int MT) {
   const int S = D * H * W, tiles = (C / 16) * 3;
   HwPlan p;
   p.lds_w = head_lds_w(C, D, H, W, MT);
-  const int want_blocks = std::max(1, 256 / tiles);
+  static const int target = getenv("MSL_HEAD_BWW_WGS") ? atoi(getenv("MSL_HEAD_BWW_WGS")) : 256;
+  const int want_blocks = std::max(1, target / tiles);
   if (p.lds_w) {
     const int total = N * (S / 64);
     p.bpw = msl::cdiv(total, std::min(want_blocks, total));
@@ -944,9 +945,13 @@ inline HwPlan head_bw_plan(int N, int C, int D, int H, int W, int MT) {
 inline int head_fwd_ksg(int N, int C, int D, int H, int W, int MT) {
   const int S = D * H * W;
   if (head_lds_w(C, D, H, W, MT)) {
+    // about one workgroup per CU.  More (MSL_HEAD_FWD_WGS / _BWD_WGS / _BWW_WGS = 512, 768: a second wave per SIMD to cover the
+    // loop's LDS-read waits) was measured 0.5-1.5 % SLOWER on the step (tools/probes/r02_headwgs.sh): the extra staging and
+    // partial slabs cost what the latency hiding gains
+    static const int target = getenv("MSL_HEAD_FWD_WGS") ? atoi(getenv("MSL_HEAD_FWD_WGS")) : 256;
     const int blocks = N * (S / 64);
     int ksg = 1;
-    while (blocks * ksg < 256 && C / (ksg * 2) >= HEAD_FWD_CH && (C / (ksg * 2)) % HEAD_FWD_CH == 0) ksg *= 2;
+    while (blocks * ksg < target && C / (ksg * 2) >= HEAD_FWD_CH && (C / (ksg * 2)) % HEAD_FWD_CH == 0) ksg *= 2;
     return ksg;
   }
   return head_ksg(N, C, S);
@@ -1070,8 +1075,9 @@ static int head_bwd_data_impl(const float* dO_pad, const float* Wb, void* g_a, i
   hipStream_t st = (hipStream_t)stream;
   const int lw = head_lds_w(C, D, H, W, MT);
   if (lw) {
+    static const int target = getenv("MSL_HEAD_BWD_WGS") ? atoi(getenv("MSL_HEAD_BWD_WGS")) : 256;
     const int blocks = N * (S / 64), ctiles = C / 16;
-    const int gy = std::max(1, std::min(ctiles, 256 / blocks));
+    const int gy = std::max(1, std::min(ctiles, target / blocks));
     const int cts = msl::cdiv(ctiles, gy);
     dim3 grid(S / 64, msl::cdiv(ctiles, cts), N);
 #define MSL_HB(W_, B_) \
