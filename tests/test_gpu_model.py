@@ -236,6 +236,49 @@ def test_full_gradients_against_oracle():
     assert worst[0][0] <= 2e-3, f"largest relative gradient errors: {worst[:5]}"
 
 
+@pytest.mark.parametrize("size,n", [((64, 64, 64), 2), ((128, 128, 128), 4)])
+def test_relu_mask_agreement_with_the_oracle(size, n):
+    """The gradient bar is 2e-3 because single activations sit within 1e-6 of the ReLU threshold and
+    ``fma(y, scale, shift) > 0`` (here) may decide them differently from torch's ``(y - mean) * invstd * gamma + beta > 0``.
+    So that a real regression cannot hide inside that bar, the masks are compared directly: for each of the 15 BatchNorm +
+    ReLU layers, the number of activations whose on/off state differs from the oracle's must stay below 2e-6 of the layer
+    (or 2 elements), and every disagreeing element must be one the oracle itself has within 1e-5 of zero.  Measured: none
+    at 64^3 x 2, one element (1.9e-6 of its layer) at 128^3 x 4."""
+    from mslesions3d_amd import _lib
+    from mslesions3d_amd._lib import ptr
+    m, o = hip_model(1, size), oracle_model(1, size)
+    x = detinit.make_volume_batch(5, n, 1, size)
+    pre = []
+    hooks = [mod.register_forward_hook(lambda mod, inp, out: pre.append(out.detach()))
+             for mod in o.modules() if isinstance(mod, torch.nn.BatchNorm3d)]
+    o.train()
+    o(x)
+    for h in hooks:
+        h.remove()
+    m.train()
+    xd = x.to(DEV)
+    m(xd)
+    pl = m._engine.plan_for(xd, True)
+    ours = [(pl.y[0], pl.bn_y[0])]
+    for i in range(1, len(pl.y)):
+        ours += [(pl.z[i], pl.bn_z[i]), (pl.y[i], pl.bn_y[i])]
+    assert len(ours) == len(pre) == 15
+    st = torch.cuda.current_stream().cuda_stream
+    worst = 0.0
+    for k, ((raw, vec), ref) in enumerate(zip(ours, pre)):
+        N, C, D, H, W = raw.shape
+        act = torch.empty_like(raw)
+        pad = torch.zeros((N, C, D + 2, H + 2, W + 2), device=DEV)
+        _lib.call("msl_bn_relu_materialize", ptr(raw), ptr(vec[0]), ptr(vec[1]), ptr(act), ptr(pad), N, C, D, H, W, st)  # relu(fma)
+        diff = (act.cpu() > 0) != (ref > 0)
+        frac = float(diff.sum()) / diff.numel()
+        worst = max(worst, frac)
+        assert int(diff.sum()) <= max(2, 2e-6 * diff.numel()), f"BatchNorm {k}: {int(diff.sum())} of {diff.numel()} ReLU masks differ from the oracle"
+        if diff.any():
+            assert float(ref[diff].abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), f"BatchNorm {k}: a mask differs away from zero"
+    print(f"[relu masks {size[0]}^3 x{n}] largest per-layer disagreement with the oracle: {worst:.2e}")
+
+
 def test_two_adam_steps_golden():
     """Two optimisation steps through the reference-shaped API (training_step inside the optimiser closure, as
     Lightning's automatic optimisation runs ssd3d.py:467-531: the scheduler steps before the update) against the
