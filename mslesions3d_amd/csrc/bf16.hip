@@ -27,6 +27,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16;
 typedef u16 u16x8 __attribute__((ext_vector_type(8)));
 typedef u16 u16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // ---- depthwise ---------------------------------------------------------------------------------------------------
 // Workgroup = (n, c) x an output tile of TD x TH x TW voxels.  The activated input tile (with halo, zero outside the
@@ -227,6 +228,172 @@ __global__ __launch_bounds__(256) void pw_fwd_bf16_kernel(const u16* __restrict_
       }
     }
   }
+}
+
+// ---- pointwise, pipelined form (S % 64 == 0, K % BK == 0) -----------------------------------------------------------------
+// Same GEMM and tile (64 rows x 64 positions, 4 waves = 2 x 2 tiles of 32 x 32) as pw_fwd_bf16_kernel, restructured around
+// what made that kernel slow (MFMA-busy 0.5 %): (1) the activation chunk keeps its memory orientation in LDS - rows = k,
+// 64 positions + pad per row, written with ONE 16-byte store per thread and group - and the MFMA operand (8 consecutive k
+// of one position) is gathered by the hardware transpose read ds_read_b64_tr_b16 (two per operand; row stride 192 B makes
+// the 32-lane halves conflict-free); the same for the weights of the bwd-data form, which arrive k-major; (2) the global
+// loads of iteration it+1 are in flight during the MFMAs of iteration it (registers), iterations = (position tile, K chunk)
+// flattened, so a workgroup that owns several position tiles never waits for a cold load between tiles; (3) BK up to
+// 128: the deep layers (K = 256 / 512 over 32-128 workgroups) take 2-4 memory round trips instead of 8-16.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int PT_BM = 64, PT_BN = 64, PT_RS = PT_BN + 32;  // LDS row stride of a k-major image: 192 bytes
+
+__device__ __forceinline__ bf16x8 pt_tr_operand(const u16* img, int krow0, int col0, int lane) {
+  // 32-column operand tile of a k-major image: lane (c = lane & 31, h = lane >> 5) gets k = krow0 + 8h .. + 7 of column col0 + c
+  const int g = lane >> 4, l = lane & 15, q = l >> 2, pp = l & 3, h = g >> 1;
+  const u16* a = img + (krow0 + 8 * h + q) * PT_RS + col0 + 16 * (g & 1) + 4 * pp;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(a + 4 * PT_RS));
+  union { s16x4 v[2]; bf16x8 b; } u;
+  u.v[0] = lo;
+  u.v[1] = hi;
+  return u.b;
+}
+
+template <int BK, bool STATS, bool TRANS_W>
+__global__ __launch_bounds__(256) void pw_bf16_tr_kernel(const u16* __restrict__ Z, const float* __restrict__ in_scale,
+                                                         const float* __restrict__ in_shift, const float* __restrict__ Wt,
+                                                         u16* __restrict__ Y, double* __restrict__ partials, int M, int K,
+                                                         int S, int tiles_per_wg, msl::BnFold fold) {
+  constexpr int NG = BK / 32;                    // 8-element groups per thread and chunk (X and W alike)
+  constexpr int WLD = BK + 8;                    // row-major weight image: k contiguous, 16-byte aligned rows
+  __shared__ __align__(16) u16 Xs[BK * PT_RS];
+  __shared__ __align__(16) u16 Ws[TRANS_W ? BK * PT_RS : PT_BM * WLD];
+  __shared__ float fsc[PB_MAXK], fsh[PB_MAXK];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
+  const int r = lane & 31, h = lane >> 5;
+  const int n = blockIdx.z, m0 = blockIdx.y * PT_BM;
+  const int tiles_img = S / PT_BN, tile0 = blockIdx.x * tiles_per_wg;
+  const int ntiles = min(tiles_per_wg, tiles_img - tile0), nk = K / BK, total = ntiles * nk;
+  const u16* Zn = Z + (size_t)n * K * S;
+  u16* Yn = Y + (size_t)n * M * S;
+  const bool folded = fold.partials != nullptr, affine = folded || in_scale != nullptr;
+  if (affine) {  // every channel's (scale, shift) once per workgroup (K <= PB_MAXK, host-checked)
+    for (int c = tid; c < K; c += 256) {
+      float a, b;
+      if (folded) {
+        float m_, i_;
+        double v_;
+        msl::bn_fold_serial(fold, c, a, b, m_, i_, v_);
+      } else {
+        a = in_scale[c];
+        b = in_shift[c];
+      }
+      fsc[c] = a;
+      fsh[c] = b;
+    }
+  }
+  u16x8 xr[NG];
+  f32x4 wr[NG][2];
+  auto issue = [&](int it) {
+    const int t = it / nk, kc = it - t * nk, k0 = kc * BK, s0 = (tile0 + t) * PT_BN;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int idx = tid + 256 * j, krow = idx >> 3, c8 = (idx & 7) * 8;
+      xr[j] = *reinterpret_cast<const u16x8*>(Zn + (size_t)(k0 + krow) * S + s0 + c8);
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int idx = tid + 256 * j;
+      const float* src;
+      if (TRANS_W) {  // k-major weights: thread -> k row, 8 consecutive m
+        const int krow = idx >> 3, c8 = (idx & 7) * 8;
+        src = Wt + (size_t)(k0 + krow) * M + (m0 + c8 < M ? m0 + c8 : 0);
+      } else {        // m-major weights: thread -> row, 8 consecutive k
+        const int row = idx / (BK / 8), k8 = (idx % (BK / 8)) * 8;
+        src = Wt + (size_t)(m0 + row < M ? m0 + row : 0) * K + k0 + k8;
+      }
+      wr[j][0] = *reinterpret_cast<const f32x4*>(src);
+      wr[j][1] = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+  };
+  f32x16 acc = {0};
+  if (total > 0) issue(0);
+  for (int it = 0; it < total; ++it) {
+    const int t = it / nk, kc = it - t * nk, k0 = kc * BK;
+    __syncthreads();  // the previous iteration's operands have been consumed (first pass: publishes fsc / fsh)
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int idx = tid + 256 * j, krow = idx >> 3, c8 = (idx & 7) * 8;
+      u16x8 o = xr[j];
+      if (affine) {
+        const float sc = fsc[k0 + krow], sh = fsh[k0 + krow];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = msl::f2bf(msl::act(msl::bf2f(o[e]), sc, sh));
+      }
+      *reinterpret_cast<u16x8*>(&Xs[krow * PT_RS + c8]) = o;
+    }
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      const int idx = tid + 256 * j;
+      u16x8 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o[e] = msl::f2bf(wr[j][0][e]);
+        o[4 + e] = msl::f2bf(wr[j][1][e]);
+      }
+      if (TRANS_W) {
+        const int krow = idx >> 3, c8 = (idx & 7) * 8;
+        *reinterpret_cast<u16x8*>(&Ws[krow * PT_RS + c8]) = o;
+      } else {
+        const int row = idx / (BK / 8), k8 = (idx % (BK / 8)) * 8;
+        *reinterpret_cast<u16x8*>(&Ws[row * WLD + k8]) = o;
+      }
+    }
+    __syncthreads();
+    if (it + 1 < total) issue(it + 1);  // in flight during the MFMAs below
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      bf16x8 a;
+      if (TRANS_W) a = pt_tr_operand(Ws, ks * 16, wm * 32, lane);
+      else a = *reinterpret_cast<const bf16x8*>(&Ws[(wm * 32 + r) * WLD + ks * 16 + 8 * h]);
+      const bf16x8 b = pt_tr_operand(Xs, ks * 16, wn * 32, lane);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+    if (kc == nk - 1) {  // D[row][col]: col = lane & 31, row = (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5)
+      const int tile = tile0 + t, col = tile * PT_BN + wn * 32 + r;
+      const int NP = gridDim.z * tiles_img * 2, pidx = (n * tiles_img + tile) * 2 + wn;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
+        const float v = acc[i];
+        if (row < M) Yn[(size_t)row * S + col] = msl::f2bf(v);
+        if (STATS) {
+          const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);
+          if (r == msl::HALF32_SUM_LANE && row < M && partials) {
+            partials[(size_t)row * NP + pidx] = (double)sm;
+            partials[((size_t)M + row) * NP + pidx] = (double)q;
+          }
+        }
+      }
+      acc = (f32x16){0};
+    }
+  }
+}
+
+// the pipelined transposed-read kernel takes whole 64-position tiles and K in whole chunks (MSL_BF16_PW_TR=0: never)
+static bool pw_tr_ok(int M, int K, int S) {
+  static const int on = getenv("MSL_BF16_PW_TR") ? atoi(getenv("MSL_BF16_PW_TR")) : 1;
+  return on && S % PT_BN == 0 && K % 32 == 0 && K <= PB_MAXK && M % 8 == 0;
+}
+template <bool STATS, bool TRANS_W>
+static void pw_tr_launch(const u16* z, const float* in_scale, const float* in_shift, const float* w, u16* y, double* partials,
+                         int N, int M, int K, int S, const msl::BnFold& fold, hipStream_t st) {
+  const int tiles_img = S / PT_BN, mtiles = msl::cdiv(M, PT_BM);
+  // several position tiles per workgroup once the launch has more than ~2 workgroups per CU (block 1: 2048 tiles)
+  const int T = std::max(1, std::min(std::min(4, tiles_img), (tiles_img * mtiles * N) / 512));
+  dim3 grid(msl::cdiv(tiles_img, T), mtiles, N);
+#define MSL_PT(BK_) hipLaunchKernelGGL((pw_bf16_tr_kernel<BK_, STATS, TRANS_W>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, \
+                                       partials, M, K, S, T, fold)
+  if (K % 128 == 0) MSL_PT(128);
+  else if (K % 64 == 0) MSL_PT(64);
+  else MSL_PT(32);
+#undef MSL_PT
 }
 
 // ---- materialise -------------------------------------------------------------------------------------------------
@@ -687,8 +854,14 @@ static const msl::BnFold pb_nofold{nullptr, 0, 0, 1.0, nullptr, nullptr, 0.f};
 static int pw_fwd_bf16_impl(const void* z, const float* in_scale, const float* in_shift, const msl::BnFold& fold, const float* w,
                             void* y, double* partials, int N, int Cin, int Cout, int S, void* stream) {
   if (N <= 0 || S <= 0 || Cin % PB_BK != 0 || Cout <= 0) return MSL_ERR_ARG;
-  dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cout, PB_BM), N);
   hipStream_t st = (hipStream_t)stream;
+  if (pw_tr_ok(Cout, Cin, S)) {
+    if (partials) pw_tr_launch<true, false>((const u16*)z, in_scale, in_shift, w, (u16*)y, partials, N, Cout, Cin, S, fold, st);
+    else pw_tr_launch<false, false>((const u16*)z, in_scale, in_shift, w, (u16*)y, partials, N, Cout, Cin, S, fold, st);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
+  dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cout, PB_BM), N);
   if (partials)
     hipLaunchKernelGGL(pw_fwd_bf16_kernel<true>, grid, dim3(256), 0, st, (const u16*)z, in_scale, in_shift, w, (u16*)y,
                        partials, Cout, Cin, S, fold);
@@ -741,6 +914,11 @@ int msl_bn_relu_materialize_bf16_pad32(const void* y, const float* scale, const 
 // dy (N,Cout,S) bf16 -> g_in (N,Cin,S) bf16 = W^T . dy   (bf16 MFMA, fp32 accumulate)
 int msl_pwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, int Cin, int Cout, int S, void* stream) {
   if (N <= 0 || S <= 0 || Cout % PB_BK != 0 || Cin % 8 != 0) return MSL_ERR_ARG;
+  if (pw_tr_ok(Cin, Cout, S)) {
+    pw_tr_launch<false, true>((const u16*)dy, nullptr, nullptr, w, (u16*)g_in, nullptr, N, Cin, Cout, S, pb_nofold, (hipStream_t)stream);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
   dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cin, PB_BM), N);
   hipLaunchKernelGGL((pw_fwd_bf16_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, nullptr, nullptr,
                      w, (u16*)g_in, nullptr, Cin, Cout, S, pb_nofold);
