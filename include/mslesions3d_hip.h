@@ -237,6 +237,14 @@ int msl_head_conv_bwd_data_bf16(const float* dO_pad, const float* Wb, void* g_a_
 int msl_head_conv_bwd_weight_bf16(const float* dO_pad, const void* a_cl, float* dloc_w, float* dcl_w, float* dloc_b,
                                   float* dcl_b, float* workspace, int N, int C, int D, int H, int W, int ncls,
                                   void* stream);
+/* the fused stem backward (msl_dwconv_s2_bwd_bnreduce_bww -> msl_bn_bwd_finalize_coef -> msl_stem_conv_bwd_weight_fused) on
+ * bf16 dL/dz and raw stem output: dL/d(stem activation) is never stored */
+int msl_dwconv_s2_bwd_bnreduce_bww_bf16(const void* dy, const float* w, const void* y_prev, const float* bn_vec,
+                                        double* bn_partials, double* w_partials, float* w_taps_t, int N, int C, int D, int H,
+                                        int W, void* stream);
+int msl_stem_conv_bwd_weight_fused_bf16(const void* dz, const float* w1_t, const void* yraw, const float* bn_vec, const float* x,
+                                        float* dw, float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
+                                        void* stream);
 int msl_stem_conv_bwd_weight_bnapply_bf16(const void* g, const void* yraw, const float* bn_vec, const float* x, float* dw,
                                           float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
                                           void* stream);

@@ -79,6 +79,8 @@ _SIGNATURES = {
     "msl_dwconv_bwd_data_s2_patch_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_wave_bf16_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_pwconv_fwd_bf16_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_dwconv_s2_bwd_bnreduce_bww_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msl_stem_conv_bwd_weight_fused_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_wave_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_pwconv_fwd_bf16_num_partials": (_I, [_I, _I]),

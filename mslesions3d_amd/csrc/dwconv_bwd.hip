@@ -342,10 +342,10 @@ __global__ __launch_bounds__(256) void dw_bwd_weight_kernel(const float* __restr
 //     output) triples as g, so it costs one more FMA per triple.
 // The consumer (msl_stem_conv_bwd_weight_fused) rebuilds g from dL/dz on the fly.  Thread = PPT patches of
 // 2 x 2 x 4 input voxels of one (n, c); fixed-order reductions, fp64 partials.
-template <int PPT>
+template <int PPT, typename T = float>
 __global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
-    const float* __restrict__ dy, const float* __restrict__ w, int C, int D, int H, int W, int OD, int OH, int OW,
-    const float* __restrict__ y_prev, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
+    const T* __restrict__ dy, const float* __restrict__ w, int C, int D, int H, int W, int OD, int OH, int OW,
+    const T* __restrict__ y_prev, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
     const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd, double* __restrict__ bn_partials,
     double* __restrict__ w_partials, float* __restrict__ w_taps_t) {
   __shared__ float red[4][32];
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
 #pragma unroll
   for (int k = 0; k < 27; ++k) wk[k] = w[c * 27 + k];
   const float sc = bn_scale[c], sh = bn_shift[c], mu = bn_mean[c], is = bn_invstd[c];
-  const float* dyc = dy + (size_t)nc * OD * OH * OW;
-  const float* yc = y_prev + (size_t)nc * D * H * W;
+  const T* dyc = dy + (size_t)nc * OD * OH * OW;
+  const T* yc = y_prev + (size_t)nc * D * H * W;
   float aw[27];
 #pragma unroll
   for (int k = 0; k < 27; ++k) aw[k] = 0.f;
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
 #pragma unroll
         for (int ww = 0; ww < 3; ++ww) {
           const bool ok = live && a + dd < OD && b + hh < OH && c2 + ww < OW;
-          const float v = dyc[ok ? ((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww : 0];
+          const float v = msl::ld1(dyc + (ok ? ((size_t)(a + dd) * OH + b + hh) * OW + c2 + ww : 0));
           dv[dd][hh][ww] = ok ? v : 0.f;
         }
     bool okp[2][2];
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
       for (int ph = 0; ph < 2; ++ph) {
         const int id = 2 * a + pd, ih = 2 * b + ph;
         okp[pd][ph] = live && id < D && ih < H;
-        yv[pd][ph] = *reinterpret_cast<const float4*>(yc + (okp[pd][ph] ? ((size_t)id * H + ih) * W + iw0 : 0));
+        yv[pd][ph] = msl::ld4(yc + (okp[pd][ph] ? ((size_t)id * H + ih) * W + iw0 : 0));
       }
 #pragma unroll
     for (int pd = 0; pd < 2; ++pd)
@@ -614,8 +614,24 @@ int msl_dwconv_s2_bwd_bnreduce_bww(const float* dy, const float* w, const float*
   if (W % 4 != 0) return MSL_ERR_UNSUPPORTED;
   const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
-  hipLaunchKernelGGL(dw_s2_bwd_reduce_bww_kernel<S2F_PPT>, grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
+  hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
                      OH, OW, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, bn_partials, w_partials, w_taps_t);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// bf16 storage: dy (dL/dz) and y_prev are bf16 tensors, bn_vec = (>= 4, C) rows [scale, shift, mean, invstd]
+int msl_dwconv_s2_bwd_bnreduce_bww_bf16(const void* dy, const float* w, const void* y_prev, const float* bn_vec,
+                                        double* bn_partials, double* w_partials, float* w_taps_t, int N, int C, int D, int H,
+                                        int W, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || !bn_vec) return MSL_ERR_ARG;
+  if (W % 4 != 0) return MSL_ERR_UNSUPPORTED;
+  const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
+  typedef msl::su16 u16;
+  hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w, C,
+                     D, H, W, OD, OH, OW, (const u16*)y_prev, bn_vec, bn_vec + C, bn_vec + 2 * C, bn_vec + 3 * C, bn_partials,
+                     w_partials, w_taps_t);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

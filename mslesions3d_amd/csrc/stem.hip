@@ -302,7 +302,7 @@ struct StemFusedSrc {
   int OD1, OH1, OW1;  // dims of dL/dz
 };
 
-// BF16ACT (MODE 0 / 1 only): dy and yraw are bf16 tensors (bf16 activation path); everything else as in fp32.
+// BF16ACT: dy (MODE 2: dL/dz of block 1) and yraw are bf16 tensors (bf16 activation path); everything else as in fp32.
 template <int CIN, int MODE, bool BF16ACT = false>
 __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                               float* __restrict__ slabs, int N, int D, int H, int W,
@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
                                                               const float* __restrict__ w1p, StemFusedSrc fs) {
   constexpr bool APPLY = MODE >= 1;
   constexpr bool FUSED = MODE == 2;
-  static_assert(!(FUSED && BF16ACT), "the fused stem backward is fp32 only");
+  constexpr unsigned ES = BF16ACT ? 2u : 4u;  // bytes per element of dy / yraw
   constexpr int NT = (CIN * 27 + 31) / 32;
   constexpr int WAVE_LDS = 32 * SB_DY_LD + CIN * 9 * SB_ROW_LD;
   extern __shared__ __align__(16) float lds[];
@@ -365,10 +365,14 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
     // need one 32-bit scalar add each instead of a 64-bit pointer computation (the kernel was bound by its SCALAR
     // instruction stream: ~1000 scalar instructions per chunk, most of them address arithmetic).
     const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)msl::uniform_base(yraw), 0, (int)((unsigned)N * 32u * (unsigned)OS * 4u), 0x00020000);
+        (void*)msl::uniform_base(yraw), 0, (int)((unsigned)N * 32u * (unsigned)OS * ES), 0x00020000);
     const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)msl::uniform_base(dy), 0, (int)((unsigned)N * 32u * (unsigned)OS1 * 4u), 0x00020000);
-    const unsigned OS4 = (unsigned)OS * 4u, OS14 = (unsigned)OS1 * 4u;
+        (void*)msl::uniform_base(dy), 0, (int)((unsigned)N * 32u * (unsigned)OS1 * ES), 0x00020000);
+    const unsigned OS4 = (unsigned)OS * ES, OS14 = (unsigned)OS1 * ES;
+    auto ldact = [](const __amdgpu_buffer_rsrc_t& rs, int voff, int soff) {  // one element of dy / yraw as fp32
+      if constexpr (BF16ACT) return msl::bf2f((unsigned short)__builtin_amdgcn_raw_buffer_load_b16(rs, voff, soff, 0));
+      else return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, voff, soff, 0));
+    };
     // the wave walks `iters` CONSECUTIVE chunks: coordinates are decoded once and then advanced with scalar increments
     // (four integer divisions per chunk otherwise), and consecutive rows share their dz rows in this CU's L1
     int w_seg, w_oh, w_od, w_n;
@@ -406,12 +410,12 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
       const int npos = c.live ? min(64, OW - c.ow0) : 0;
       c.in = lane < npos;
       const int ly = c.in ? lane : 0;
-      c.ly4 = ly * 4;
+      c.ly4 = ly * (int)ES;
       const int ow = c.ow0 + ly;
       c.odd = ow & 1;
       const int jl = (ow >> 1) + (ow & 1);
       c.okl = jl < fs.OW1;
-      c.ldz4 = (c.okl ? jl : 0) * 4;
+      c.ldz4 = (c.okl ? jl : 0) * (int)ES;
       const bool pd = c.od & 1, ph = c.oh & 1;
       int idD[2], idH[2];
       idD[0] = pd ? (c.od + 1) >> 1 : c.od >> 1; c.kD[0] = pd ? 0 : 1; c.vD[0] = idD[0] < fs.OD1;
@@ -420,23 +424,23 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
       idH[1] = c.oh >> 1;                         c.kH[1] = 2;          c.vH[1] = ph;
       if (!c.vD[0]) idD[0] = c.od >> 1;  // dead slots re-read a live row
       if (!c.vH[0]) idH[0] = c.oh >> 1;
-      c.yrow4 = ((unsigned)(c.n * 32) * (unsigned)OS + (unsigned)((c.od * OH + c.oh) * OW + c.ow0)) * 4u;
+      c.yrow4 = ((unsigned)(c.n * 32) * (unsigned)OS + (unsigned)((c.od * OH + c.oh) * OW + c.ow0)) * ES;
       const unsigned dzn = (unsigned)(c.n * 32) * (unsigned)OS1;
 #pragma unroll
-      for (int t = 0; t < 4; ++t) c.dzrow4[t] = (dzn + (unsigned)((idD[t >> 1] * fs.OH1 + idH[t & 1]) * fs.OW1)) * 4u;
+      for (int t = 0; t < 4; ++t) c.dzrow4[t] = (dzn + (unsigned)((idD[t >> 1] * fs.OH1 + idH[t & 1]) * fs.OW1)) * ES;
       return c;
     };
     auto issue = [&](const Ctx& c, int cg, float (&yv)[8], float (&dz)[8][4]) {
       unsigned o = c.yrow4 + (unsigned)(cg * 8) * OS4;  // scalar, advanced by one channel per load
 #pragma unroll
       for (int k = 0; k < 8; ++k, o += OS4)
-        yv[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(ry, c.ly4, (int)o, 0));
+        yv[k] = ldact(ry, c.ly4, (int)o);
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         unsigned q = c.dzrow4[t] + (unsigned)(cg * 8) * OS14;
 #pragma unroll
         for (int k = 0; k < 8; ++k, q += OS14)
-          dz[k][t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rdz, c.ldz4, (int)q, 0));
+          dz[k][t] = ldact(rdz, c.ldz4, (int)q);
       }
     };
     auto consume = [&](const Ctx& c, int cg, const float (&yv)[8], const float (&dz)[8][4]) {
@@ -782,6 +786,19 @@ int msl_stem_conv_bwd_weight_bnapply(const float* g, const float* yraw, const fl
   return stem_bww_impl(g, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, yraw, bn_vec, nullptr, stream);
 }
 
+// bf16 activation path: dz (dL/dz of block 1) and yraw are bf16 tensors; otherwise msl_stem_conv_bwd_weight_fused
+int msl_stem_conv_bwd_weight_fused_bf16(const void* dz, const float* w1_t, const void* yraw, const float* bn_vec, const float* x,
+                                        float* dw, float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
+                                        void* stream) {
+  if (!dz || !w1_t || !yraw || !bn_vec) return MSL_ERR_ARG;
+  {
+    const long long OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
+    if ((long long)N * 32 * OD * OH * OW * 2 >= (1ll << 32)) return MSL_ERR_UNSUPPORTED;
+  }
+  return stem_bww_impl((const float*)dz, x, dw, workspace, N, Cin, D, H, W, sd, sh, sw, (const float*)yraw, bn_vec, w1_t, stream,
+                       true);
+}
+
 // bf16 activation path: g (dL/d relu(bn(y))) and yraw are bf16 tensors; same slabs / reduction as msl_stem_conv_bwd_weight_bnapply
 int msl_stem_conv_bwd_weight_bnapply_bf16(const void* g, const void* yraw, const float* bn_vec, const float* x, float* dw,
                                           float* workspace, int N, int Cin, int D, int H, int W, int sd, int sh, int sw,
@@ -828,8 +845,8 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
 #define MSL_STEM_BW(CI)                                \
   do {                                                 \
     if (bf16act) {                                     \
-      if (w1) return MSL_ERR_UNSUPPORTED;              \
-      if (yraw) MSL_STEM_BW1B(CI, 1);                  \
+      if (w1) MSL_STEM_BW1B(CI, 2);                    \
+      else if (yraw) MSL_STEM_BW1B(CI, 1);             \
       else MSL_STEM_BW1B(CI, 0);                       \
     } else if (w1) MSL_STEM_BW1(CI, 2);                \
     else if (yraw) MSL_STEM_BW1(CI, 1);                \

@@ -592,8 +592,18 @@ class Engine:
                           2 * specs[i]["cin"] * max(L.msl_dwconv_bwd_data_bnreduce_num_partials(N, specs[i]["cin"], pd, ph, pw), 0))
             d0 = pl.dims[0]
             bnp = max(bnp, 2 * specs[0]["cout"] * L.msl_bn_relu_bwd_bf16_num_partials(N, d0[0] * d0[1] * d0[2]))
-            pl.partials = torch.empty(bnp, **f64)
             pl.fused_stem_np = -1
+            if (len(specs) > 1 and specs[0]["cout"] == 32 and specs[1]["cin"] == 32 and tuple(specs[1]["stride"]) == (2, 2, 2)
+                    and 0 not in pl.feat_ids and self.fuse_stem):
+                # fused stem backward on bf16 storage: dL/d(stem activation) is never stored (as in the fp32 step)
+                np_f = L.msl_dwconv_s2_bwd_bnreduce_bww_num_partials(N, 32, *pl.dims[0])
+                if np_f > 0 and pl.y[0].numel() * 2 < (1 << 32):
+                    pl.fused_stem_np = np_f
+                    pl.partials_wf = torch.empty(32 * 27 * np_f, **f64)
+                    pl.w1_taps_t = torch.empty((27, 32), **f32)
+                    bnp = max(bnp, 2 * 32 * np_f)
+                    pl.g_y[0] = None  # never materialised
+            pl.partials = torch.empty(bnp, **f64)
             pl.grad_tables = {}
         self.plans[key] = pl
         return pl
@@ -780,7 +790,14 @@ class Engine:
             if accumulate and (i - 1) in side_feats:
                 self._wait(st, pl.events[f"head_done{i - 1}"])
             Sp = pd * ph * pw
-            if s == 2 and pw % 4 == 0 and not self._bn_bwd_bf16_fused(N, Sp):
+            fused_stem = i == 1 and pl.fused_stem_np > 0
+            if fused_stem:
+                # one pass over (dL/dz_1, y_0): the stem's BatchNorm-backward sums + this block's depthwise weight gradient;
+                # the stem weight gradient below rebuilds dL/d(stem activation) from dL/dz_1 on the fly
+                self._k("dw_bwd1", "msl_dwconv_s2_bwd_bnreduce_bww_bf16", ptr(pl.g_z[1]), ptr(feats[1].conv1.weight), ptr(pl.y[0]),
+                        ptr(pl.bn_y[0]), ptr(pl.partials), ptr(pl.partials_wf), ptr(pl.w1_taps_t), N, 32, pd, ph, pw, st)
+                pre_np = pl.fused_stem_np
+            elif s == 2 and pw % 4 == 0 and not self._bn_bwd_bf16_fused(N, Sp):
                 # big producer layer: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
                 pre_np = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, sp["cin"], pd, ph, pw)
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_s2_patch_bf16", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight),
@@ -792,8 +809,9 @@ class Engine:
             out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
             self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs_bf16", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
                     ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, sX)
-            self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
-                    ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, sX)
+            if not fused_stem:  # (its partials came with the fused pass: pl.partials_wf)
+                self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
+                        ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, sX)
         # stem: BatchNorm-backward sums, then the weight gradient with the BatchNorm backward applied on load
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
@@ -803,10 +821,16 @@ class Engine:
         if pre_np is None:
             self._k("bn_bwd_reduce:stem", "msl_bn_relu_bwd_reduce_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec[0]), ptr(vec[1]),
                     ptr(vec[2]), ptr(vec[3]), ptr(pl.partials), N, specs[0]["cout"], S0, st)
-        _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(N * S0), ptr(gv["base.features.0.1.weight"]),
-                  ptr(gv["base.features.0.1.bias"]), ptr(vec[4]), ptr(vec[5]), specs[0]["cout"], st)
-        self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec), ptr(pl.saved_input),
-                None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        if pl.fused_stem_np > 0:
+            _lib.call("msl_bn_bwd_finalize_coef", ptr(pl.partials), NP, float(N * S0), ptr(gv["base.features.0.1.weight"]),
+                      ptr(gv["base.features.0.1.bias"]), ptr(vec), specs[0]["cout"], st)
+            self._k("stem_bww", "msl_stem_conv_bwd_weight_fused_bf16", ptr(pl.g_z[1]), ptr(pl.w1_taps_t), ptr(pl.y[0]), ptr(vec),
+                    ptr(pl.saved_input), None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        else:
+            _lib.call("msl_bn_bwd_finalize", ptr(pl.partials), NP, float(N * S0), ptr(gv["base.features.0.1.weight"]),
+                      ptr(gv["base.features.0.1.bias"]), ptr(vec[4]), ptr(vec[5]), specs[0]["cout"], st)
+            self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply_bf16", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(vec), ptr(pl.saved_input),
+                    None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
         if ms:  # every gradient is complete once the side streams have been joined
             self._fork(pl, "bwd_join_w", stW, st)
             self._fork(pl, "bwd_join_h", stH, st)

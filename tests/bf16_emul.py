@@ -55,11 +55,12 @@ def _bn_bwd(g, yb, vec, gamma):
     return dy.float(), dgamma.float(), dbeta.float()
 
 
-def emulated_step(om, x, dlocs=None, dscores=None, f32_heads=True):
+def emulated_step(om, x, dlocs=None, dscores=None, f32_heads=True, fused_stem=True):
     """Forward (train mode, batch statistics) of the oracle model ``om`` under bf16 storage; with upstream gradients also
     the backward.  Returns (locs, scores, grads) with grads keyed like ``om.named_parameters()`` (None without upstream).
     ``f32_heads``: the training step's head convolutions run on the fp32 kernels (fp32 feature copy, unrounded weights);
-    False: the bf16 head kernel of the inference path (bf16 feature copy and weights)."""
+    False: the bf16 head kernel of the inference path (bf16 feature copy and weights).  ``fused_stem``: the gradient of the stem
+    activation is rebuilt on the fly from dL/dz of block 1 and never stored, hence never rounded (cubic inputs)."""
     feats = om.base.features
     nblk = len(feats)
     N = x.shape[0]
@@ -126,7 +127,7 @@ def emulated_step(om, x, dlocs=None, dscores=None, f32_heads=True):
         w1 = P[n + ".conv1.weight"]
         G[n + ".conv1.weight"] = torch.nn.grad.conv3d_weight(a_in, w1.shape, dz, stride=s, padding=1, groups=a_in.shape[1])
         gin = torch.nn.grad.conv3d_input(a_in.shape, w1, dz, stride=s, padding=1, groups=a_in.shape[1])
-        gy[i - 1] = bfg(gin if gy[i - 1] is None else gy[i - 1] + gin)
+        gy[i - 1] = gin if (i == 1 and fused_stem) else bfg(gin if gy[i - 1] is None else gy[i - 1] + gin)
     # stem: the weight gradient applies the BatchNorm backward on load, in fp32 (nothing is rounded in between)
     dy, G["base.features.0.1.weight"], G["base.features.0.1.bias"] = _bn_bwd(gy[0], yb[0], vy[0], P["base.features.0.1.weight"])
     w0 = P["base.features.0.0.weight"]

@@ -283,6 +283,52 @@ def test_dw_s2_bwd_data_with_bn_reduce_bf16(N, C, dims):
     close(dbet, beta.grad, 1e-3, tol, "dbeta from the fused reduce")
 
 
+@pytest.mark.parametrize("cin,dims", [(1, (12, 16, 24)), (2, (16, 16, 16)), (1, (32, 32, 32))])
+def test_fused_stem_backward_bf16(cin, dims):
+    """The fused stem backward on bf16 storage: one pass over (dL/dz_1, y_0) for the stem's BatchNorm sums and block 1's
+    depthwise weight gradient, then the stem weight gradient rebuilding dL/d(stem activation) from dL/dz_1 on the fly ==
+    CPU autograd through conv -> BN -> ReLU -> depthwise conv on the same bf16-rounded y_0 / dL/dz_1."""
+    L = _lib.load()
+    N = 2
+    x = rnd(N, cin, *dims, seed=1)
+    w0 = rnd(32, cin, 3, 3, 3, seed=2, scale=0.3)
+    gamma = (rnd(32, seed=3).abs() + 0.5).requires_grad_(True)
+    beta = rnd(32, seed=4, scale=0.2).requires_grad_(True)
+    w1 = rnd(32, 1, 3, 3, 3, seed=5, scale=0.4).requires_grad_(True)
+    y0 = bfr(F.conv3d(x, w0, stride=2, padding=1)).requires_grad_(True)  # what the bf16 forward stored
+    a0 = torch.relu(F.batch_norm(y0, None, None, gamma, beta, True, 0.1, 1e-5))
+    z1 = F.conv3d(a0, w1, stride=2, padding=1, groups=32)
+    dz = bfr(rnd(*z1.shape, seed=6))
+    z1.backward(dz)
+    refdw0 = torch.nn.grad.conv3d_weight(x, w0.shape, y0.grad, stride=2, padding=1)
+    od, oh, ow = y0.shape[2:]
+    S0 = od * oh * ow
+    yd = y0.detach().double()
+    part = torch.stack([yd.sum((0, 2, 3, 4)), (yd ** 2).sum((0, 2, 3, 4))]).view(2, 32, 1).contiguous().to(DEV)
+    vec = torch.zeros((8, 32), device=DEV)
+    _lib.call("msl_bn_finalize", ptr(part), 1, float(N * S0), ptr(K(gamma.detach())), ptr(K(beta.detach())), None, None, None, 0.1,
+              1e-5, ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]), 32, st())
+    NP = L.msl_dwconv_s2_bwd_bnreduce_bww_num_partials(N, 32, od, oh, ow)
+    assert NP > 0
+    bp = torch.full((2 * 32 * NP,), float("nan"), dtype=torch.float64, device=DEV)
+    wp = torch.full((32 * 27, NP), float("nan"), dtype=torch.float64, device=DEV)
+    w1t = torch.full((27, 32), float("nan"), device=DEV)
+    y0d, dzd = b16(y0.detach()), b16(dz)
+    _lib.call("msl_dwconv_s2_bwd_bnreduce_bww_bf16", ptr(dzd), ptr(K(w1.detach())), ptr(y0d), ptr(vec), ptr(bp), ptr(wp), ptr(w1t),
+              N, 32, od, oh, ow, st())
+    assert torch.equal(w1t.cpu(), w1.detach().view(32, 27).t())
+    dgam, dbet = torch.empty(32, device=DEV), torch.empty(32, device=DEV)
+    _lib.call("msl_bn_bwd_finalize_coef", ptr(bp), NP, float(N * S0), ptr(dgam), ptr(dbet), ptr(vec), 32, st())
+    close(dgam, gamma.grad, 1e-4, 1e-4, "dgamma")
+    close(dbet, beta.grad, 1e-4, 1e-4, "dbeta")
+    close(wp.sum(1).float().view(32, 1, 3, 3, 3), w1.grad, 1e-4, 1e-4, "depthwise dW from the fused pass")
+    dw = torch.full((32, cin, 3, 3, 3), float("nan"), device=DEV)
+    ws = torch.empty(L.msl_stem_conv_bwd_weight_workspace_bytes(cin) // 4, device=DEV)
+    _lib.call("msl_stem_conv_bwd_weight_fused_bf16", ptr(dzd), ptr(w1t), ptr(y0d), ptr(vec), ptr(K(x)), ptr(dw), ptr(ws), N, cin,
+              *dims, 2, 2, 2, st())
+    close(dw, refdw0, 2e-4, 1e-4 * max(1.0, float(refdw0.abs().max())), "stem dW with the gradient rebuilt on the fly (bf16 dz, y0)")
+
+
 @pytest.mark.parametrize("N,C,S", [(3, 8, 192), (2, 64, 4096), (4, 32, 32768), (1, 16, 100), (2, 512, 64), (4, 16, 8192),
                                    (2, 8, 16384), (4, 128, 4096), (1, 8, 24)])
 def test_bn_relu_bwd_bf16(N, C, S):
