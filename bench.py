@@ -213,7 +213,7 @@ def main():
             variant = _lib.load().msl_dwconv_fwd_variant(args.batch, C1, *d0, 2)
             dw1_kernel = {3: "dw_s2_wave_kernel<4,5,4>", 1: "dw_fwd_stream_kernel<2,1,4,0>"}.get(variant, f"dwconv variant {variant}")
         else:
-            dw1_kernel = "dw_fwd_bf16_kernel<2>"
+            dw1_kernel = "dw_s2_wave_kernel<4,5,4,bf16>"  # the fp32 wave kernel templated on the storage type
         # committed rocprofv3 measurements of THIS kernel on this workload (tools/summarize_profiles.py): PMC bytes per
         # launch and the kernel-trace duration.  Constants of the named profile, not something this run measured.
         traffic, traffic_src, frac_rocprof, agg_rocprof = None, None, None, None

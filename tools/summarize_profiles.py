@@ -85,8 +85,10 @@ print("\n".join(out[:20]))
 if args.traffic_json:
     # block 1's depthwise forward (the bench line's roofline kernel) + the seven forward depthwise launches of a step, in
     # launch order, from the kernel trace (stride-1 kernels also run as bwd-data launches: the trace tells them apart)
-    pat = "dw_fwd_bf16_kernel<2>" if bench.get("dtype") == "bf16" else "dw_s2_wave_kernel<4, 5, 4>"
-    key = [r for r in rows if r["name"] == pat]
+    bf16 = bench.get("dtype") == "bf16"
+    canon = "dw_s2_wave_kernel<4,5,4,bf16>" if bf16 else "dw_s2_wave_kernel<4,5,4>"  # the name bench.py quotes
+    key = [r for r in rows if r["name"].startswith("dw_s2_wave_kernel<4, 5, 4") and
+           (("unsigned short" in r["name"]) == bf16)]
     tr = list(csv.DictReader(open(os.path.join(src, "kernel_trace.csv"))))
     tr.sort(key=lambda r: int(r["Start_Timestamp"]))
     ends = [i for i, r in enumerate(tr) if "adam_kernel" in r["Kernel_Name"]]
@@ -98,7 +100,7 @@ if args.traffic_json:
             for i, r in enumerate(dws):
                 per_layer[i].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     lay = [sum(v) / len(v) for v in per_layer] if all(per_layer) else None
-    esz = 2.0 if bench.get("dtype") == "bf16" else 4.0
+    esz = 2.0 if bf16 else 4.0
     dims = [64 ** 3, 32 ** 3, 16 ** 3, 16 ** 3, 8 ** 3, 8 ** 3, 4 ** 3, 4 ** 3]
     chans = [32, 64, 128, 128, 256, 256, 512]
     lay_b = [esz * 4 * c * (dims[i] + dims[i + 1]) + 4.0 * c * 27 for i, c in enumerate(chans)]
@@ -111,7 +113,7 @@ if args.traffic_json:
             agg = {"sum_launch_us": round(sum(lay), 2), "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4),
                    "per_layer_us": [round(u, 2) for u in lay], "profile": f"profiles/{tag}_kernel_stats.csv (kernel trace of the same run)"}
         json.dump({
-            "kernel": pat.replace(" ", ""), "round": 2, "profile": tag, "FETCH_SIZE_kb_avg": r["fk"], "WRITE_SIZE_kb_avg": r["wk"],
+            "kernel": canon, "round": 2, "profile": tag, "FETCH_SIZE_kb_avg": r["fk"], "WRITE_SIZE_kb_avg": r["wk"],
             "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16-B/lane streaming reads -> x2 "
                           "(MI355X_MICROARCH.md, HBM); WRITE_SIZE exact",
             "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": lay_b[0], "avg_launch_us_rocprof": round(r["us"], 2),
