@@ -128,6 +128,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 
   float wa[KS];
   int tapoff[KS];  // element offset of the lane's tap kk inside the image
+  int lowtap[KS];  // bit 0 / 1 / 2: the tap sits on the low (-1) side in d / h / w: outside the volume on a low-border tile
 #pragma unroll
   for (int kk = 0; kk < KS; ++kk) {
     const int k = 2 * kk + h;
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
     const int ci = k / 27, t = k % 27, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
     wa[kk] = vk ? w[c * K + (vk ? k : 0)] : 0.f;
     tapoff[kk] = vk ? ((ci * D + kd) * H + kh) * W + kw : 0;
+    lowtap[kk] = vk ? (kd == 0 ? 1 : 0) | (kh == 0 ? 2 : 0) | (kw == 0 ? 4 : 0) : 0;
   }
   float ssum[16], qsum[16];
 #pragma unroll
@@ -201,10 +203,25 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
     const int rowbase = (id0 * H + ih0) * W - 1;
     const int ow = owt + c;
     const bool rows_in = id0 >= 0 && id0 + 2 < D && ih0 >= 0 && ih0 + 2 < H;
+    const bool high_in = id0 + 2 < D && ih0 + 2 < H && (owt + 31) * sw + 1 < W;  // nothing beyond the high faces
     if (t.live && rows_in && owt >= 1 && (owt + 31) * sw + 1 < W) {  // wave-uniform: every tap of every lane is inside
       const int soff = __builtin_amdgcn_readfirstlane((rowbase + owt * sw) * 4);
 #pragma unroll
       for (int kk = 0; kk < KS; ++kk) b[kk] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, lanetap4[kk], soff, 0));
+    } else if (t.live && high_in) {
+      // Low-border tile (first plane / first row / first 32 columns: with stride 2 and even sizes that is every other
+      // tile of a row): only the taps on the -1 side can be outside, and which ones is known per lane and k-step.  Same
+      // loads as the interior path; an outside tap is fetched one voxel further in along every axis (always inside the
+      // image) and replaced by zero - no per-tap coordinate arithmetic.
+      const int base4 = (rowbase + owt * sw) * 4;          // may be negative: folded into the per-lane offset
+      const int shift4 = ((H + 1) * W + 1) * 4;
+      const int lowmask = (id0 < 0 ? 1 : 0) | (ih0 < 0 ? 2 : 0) | ((owt == 0 && c == 0) ? 4 : 0);
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) {
+        const bool out = (lowtap[kk] & lowmask) != 0;
+        const float v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, lanetap4[kk] + base4 + (out ? shift4 : 0), 0, 0));
+        b[kk] = out ? 0.f : v;
+      }
     } else {
       const bool pv = t.live && ow < OW;
       const int iw0 = ow * sw - 1;
