@@ -212,7 +212,12 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
       // Low-border tile (first plane / first row / first 32 columns: with stride 2 and even sizes that is every other
       // tile of a row): only the taps on the -1 side can be outside, and which ones is known per lane and k-step.  Same
       // loads as the interior path; an outside tap is fetched one voxel further in along every axis (always inside the
-      // image) and replaced by zero - no per-tap coordinate arithmetic.
+      // image) and replaced by zero - no per-tap coordinate arithmetic (49 -> 44 us alone at 128^3 x 4).
+      // Ablation of the result (tools/probes/r02_stemabl.sh): of 45 us the 14 stride-2 gathers of a tile cost 17.6, the
+      // MFMAs 12, the 16 stores 8, the statistics 1.6 - the kernel is bound by vector-memory INSTRUCTION issue (~24
+      // cycles per gather, ~9 per store and CU), not by bytes: bf16 output takes the same time.  Tried and dropped: a
+      // third register set (two tiles of look-ahead: 191 VGPRs, occupancy 2, 52 us); the transposed product with four
+      // 16-byte stores per lane (32-byte segments per channel: 48 us); 384-2048 workgroups per image (55-75 us).
       const int base4 = (rowbase + owt * sw) * 4;          // may be negative: folded into the per-lane offset
       const int shift4 = ((H + 1) * W + 1) * 4;
       const int lowmask = (id0 < 0 ? 1 : 0) | (ih0 < 0 ? 2 : 0) | ((owt == 0 && c == 0) ? 4 : 0);
