@@ -447,16 +447,16 @@ __global__ __launch_bounds__(64) void head_bias_reduce_kernel(const float* __res
 // LDS with coalesced loads (prefetched into registers one chunk ahead), and every MFMA operand is a conflict-free
 // ds_read_b32 (128 B/clk/CU, no tag lookup).  Blocks: W = 16 -> 4 rows of a plane, W = 8 -> a plane, W = 4 -> 4 planes.
 // staging helpers: arrays by reference into force-inlined functions stay in registers (a lambda capturing them did not)
-template <int NA>
+template <int NA, int NT = 256>
 __device__ __forceinline__ void head_ld_f4(f32x4 (&av)[NA], const f32x4* __restrict__ wp, int tid, int total) {
 #pragma unroll
-  for (int i = 0; i < NA; ++i) av[i] = wp[min(tid + 256 * i, total - 1)];
+  for (int i = 0; i < NA; ++i) av[i] = wp[min(tid + NT * i, total - 1)];
 }
-template <int NA>
+template <int NA, int NT = 256>
 __device__ __forceinline__ void head_st_f4(const f32x4 (&av)[NA], float* __restrict__ dst, int tid, int total) {
 #pragma unroll
   for (int i = 0; i < NA; ++i)
-    if (tid + 256 * i < total) reinterpret_cast<f32x4*>(dst)[tid + 256 * i] = av[i];
+    if (tid + NT * i < total) reinterpret_cast<f32x4*>(dst)[tid + NT * i] = av[i];
 }
 template <int NS>
 __device__ __forceinline__ void head_ld_f1(float (&sv)[NS], const float* __restrict__ ap, const int (&goff)[NS]) {
@@ -497,21 +497,29 @@ __device__ __forceinline__ int head_block_off(int pb) {
 // chunk's loads are issued one chunk ahead: a chunk must hold about as much MFMA time (27 per k-group of 4 channels,
 // 32 cycles each) as an L2 round trip takes under load (~1.5 us), or every chunk waits for its loads - 16 channels.
 constexpr int HEAD_FWD_CH = 16;
+// Eight waves per workgroup: two per 16-position tile, each contracting half of a chunk's channel groups, so that every
+// SIMD holds two waves and one wave's LDS-operand waits are covered by the other's MFMAs.  (Ablation of the four-wave
+// form at 16^3 x 4, C = 128: 30.7 us = 11.5 MFMA + 10 B-operand reads + 6.5 A-operand reads + staging, back to back: with
+// one wave per SIMD nothing hides a wait.  More workgroups per CU did not help: they duplicate the staging.)
+constexpr int HEAD_FWD_NT = 512;
 template <int W, int MT>
-__global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restrict__ a_pad, const float* __restrict__ Wf,
-                                                           const float* __restrict__ loc_b, const float* __restrict__ cl_b,
-                                                           float* __restrict__ locs, float* __restrict__ scores,
-                                                           float* __restrict__ slabs, int C, int D, int Ptot,
-                                                           int prior_off, int ncls, int co_total, int KSG) {
+__global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* __restrict__ a_pad, const float* __restrict__ Wf,
+                                                                   const float* __restrict__ loc_b, const float* __restrict__ cl_b,
+                                                                   float* __restrict__ locs, float* __restrict__ scores,
+                                                                   float* __restrict__ slabs, int C, int D, int Ptot,
+                                                                   int prior_off, int ncls, int co_total, int KSG) {
   typedef HeadGeo<W> G;
+  constexpr int NT = HEAD_FWD_NT;
   constexpr int SLAB = G::PD * G::PH * G::PW, CH = HEAD_FWD_CH, NCG = CH / 4;
-  constexpr int NS = (CH * SLAB + 255) / 256;          // slab floats per thread and chunk
+  constexpr int NS = (CH * SLAB + NT - 1) / NT;        // slab floats per thread and chunk
   constexpr int AF4 = NCG * 27 * MT * 64 / 4;          // weight fragments of a chunk, in float4
-  constexpr int NA = (AF4 + 255) / 256;
+  constexpr int NA = (AF4 + NT - 1) / NT;
+  static_assert(NCG % 2 == 0, "two waves share a tile's channel groups");
   __shared__ __align__(16) float slab[CH * G::CS];
   __shared__ __align__(16) float afr[AF4 * 4];
   const int n = blockIdx.y, ksg = blockIdx.z, b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
+  const int tile = wv & 3, khalf = wv >> 2;
   const int S = D * W * W, Hp = W + 2;
   const size_t volp = (size_t)(D + 2) * Hp * Hp;
   int d0, h0;
@@ -521,7 +529,7 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
   int goff[NS], loff[NS];
 #pragma unroll
   for (int i = 0; i < NS; ++i) {
-    const int e = tid + 256 * i;
+    const int e = tid + NT * i;
     const int ch = e / SLAB, r = e % SLAB;
     const int pd = r / (G::PH * G::PW), ph = (r / G::PW) % G::PH, pw = r % G::PW;
     goff[i] = e < CH * SLAB ? (int)(ch * volp) + ((d0 + pd) * Hp + h0 + ph) * Hp + pw : -1;
@@ -531,26 +539,27 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
   const f32x4* wbase = reinterpret_cast<const f32x4*>(Wf + (size_t)(c_begin / 4) * 27 * MT * 64);
   float sv[NS];
   f32x4 av[NA];
-  const int ob = head_block_off<W>(wv * 16 + j);
+  const int ob = head_block_off<W>(tile * 16 + j);
   // two accumulator chains per output tile (even / odd taps): a 16x16x4 fp32 MFMA issues every 32 cycles but a dependent
-  // one only every 40, and a wave has one tile
+  // one only every 40
   f32x4 acc[MT], acc2[MT];
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] = acc2[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   head_ld_f1(sv, abase, goff);
-  head_ld_f4(av, wbase, tid, AF4);
+  head_ld_f4<NA, NT>(av, wbase, tid, AF4);
   for (int ck = 0; ck < nchunks; ++ck) {
     __syncthreads();  // the previous chunk has been consumed
     head_st_f1(sv, slab, goff, loff);
-    head_st_f4(av, afr, tid, AF4);
+    head_st_f4<NA, NT>(av, afr, tid, AF4);
     __syncthreads();
     if (ck + 1 < nchunks) {  // in flight during this chunk's MFMAs
       head_ld_f1(sv, abase + (size_t)(ck + 1) * CH * volp, goff);
-      head_ld_f4(av, wbase + (size_t)(ck + 1) * AF4, tid, AF4);
+      head_ld_f4<NA, NT>(av, wbase + (size_t)(ck + 1) * AF4, tid, AF4);
     }
 #pragma unroll
-    for (int cgl = 0; cgl < NCG; ++cgl) {
+    for (int cg2 = 0; cg2 < NCG / 2; ++cg2) {
+      const int cgl = khalf * (NCG / 2) + cg2;
       const float* sp = slab + (cgl * 4 + q) * G::CS + ob;
       const float* fp = afr + (size_t)cgl * 27 * MT * 64 + lane;
 #pragma unroll
@@ -571,7 +580,18 @@ __global__ __launch_bounds__(256) void head_fwd_lds_kernel(const float* __restri
   }
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] += acc2[m];
-  const int P = b * 64 + wv * 16 + j;
+  // the two waves of a tile meet in LDS (the slab region is free now): fixed order, first half + second half
+  __syncthreads();
+  f32x4* xch = reinterpret_cast<f32x4*>(slab);
+  if (khalf == 1) {
+#pragma unroll
+    for (int m = 0; m < MT; ++m) xch[(tile * MT + m) * 64 + lane] = acc[m];
+  }
+  __syncthreads();
+  if (khalf == 1) return;
+#pragma unroll
+  for (int m = 0; m < MT; ++m) acc[m] += xch[(tile * MT + m) * 64 + lane];
+  const int P = b * 64 + tile * 16 + j;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if (KSG == 1) {
@@ -1035,7 +1055,7 @@ int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, c
   if (lw) {
     dim3 grid(S / 64, N, ksg);
 #define MSL_HF(W_, MT_)                                                                                              \
-  hipLaunchKernelGGL((head_fwd_lds_kernel<W_, MT_>), grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores,   \
+  hipLaunchKernelGGL((head_fwd_lds_kernel<W_, MT_>), grid, dim3(HEAD_FWD_NT), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, \
                      workspace, C, D, Ptot, prior_off, ncls, co_total, ksg)
     if (lw == 16) MSL_HF(16, 1); else if (lw == 8) MSL_HF(8, 1); else MSL_HF(4, 1);
 #undef MSL_HF
