@@ -705,6 +705,11 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_reduce_kernel(const float
 }
 
 constexpr int STEM_BW_BLOCKS = 512;
+// workgroups of the stem weight gradient (= partial slabs): two per CU by default; MSL_STEM_BWW_BLOCKS for A/B
+static inline int stem_bw_blocks() {
+  static const int v = getenv("MSL_STEM_BWW_BLOCKS") ? atoi(getenv("MSL_STEM_BWW_BLOCKS")) : STEM_BW_BLOCKS;
+  return v > 0 ? v : STEM_BW_BLOCKS;
+}
 
 }  // namespace
 
@@ -763,14 +768,14 @@ int msl_stem_conv_fwd_bf16(const float* x, const float* w, void* y_bf16, double*
 
 size_t msl_stem_conv_bwd_weight_workspace_bytes(int Cin) {
   const int NT = (Cin * 27 + 31) / 32;
-  return (size_t)STEM_BW_BLOCKS * 32 * 32 * NT * sizeof(float);
+  return (size_t)stem_bw_blocks() * 32 * 32 * NT * sizeof(float);
 }
 
 // number of [32][32*NT] slabs the stem weight-gradient kernels leave in `workspace` (NT = ceil(Cin*27 / 32))
 int msl_stem_conv_bwd_weight_nslabs(int N, int D, int H, int W, int sd, int sh, int sw) {
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || sd < 1 || sh < 1 || sw < 1) return MSL_ERR_ARG;
   const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
-  return std::min(STEM_BW_BLOCKS, msl::cdiv(N * OD * OH * msl::cdiv(OW, 64), 4));
+  return std::min(stem_bw_blocks(), msl::cdiv(N * OD * OH * msl::cdiv(OW, 64), 4));
 }
 
 // dw (32,Cin,3,3,3) = correlation of dy (N,32,OD,OH,OW) with x (N,Cin,D,H,W).  For all three forms: dw == NULL leaves
@@ -838,7 +843,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
   const int OD = (D - 1) / sd + 1, OH = (H - 1) / sh + 1, OW = (W - 1) / sw + 1;
   const int chunks_per_row = msl::cdiv(OW, 64);
   const int total_chunks = N * OD * OH * chunks_per_row;
-  const int nblocks = std::min(STEM_BW_BLOCKS, msl::cdiv(total_chunks, 4));
+  const int nblocks = std::min(stem_bw_blocks(), msl::cdiv(total_chunks, 4));
   const int iters = msl::cdiv(total_chunks, nblocks * 4);
   hipStream_t st = (hipStream_t)stream;
   const int NT = (Cin * 27 + 31) / 32;

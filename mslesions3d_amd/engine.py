@@ -235,7 +235,11 @@ class Engine:
         self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
         self.extra = {}
         self.early_pw_bww = os.environ.get("MSL_EARLY_PW_BWW", "0") == "1"
-        self.fold_bf16 = os.environ.get("MSL_BF16_FOLD", "1") == "1"  # bf16 step: BatchNorm finalize folded into consumers
+        self.fold_bf16 = os.environ.get("MSL_BF16_FOLD", "1") == "1"
+        # bf16 path: head convolutions on the fp32 kernels from an fp32 feature copy ("f32", default: measured faster at every
+        # size tried - 46 vs 32 us per scale at 192^3 x 2, 100 vs 28 us at 16^3 x 4 - and no second rounding of the head
+        # operands) or on the bf16 MFMA kernel from a channels-last bf16 copy ("bf16", inference only)
+        self.bf16_heads = os.environ.get("MSL_BF16_HEADS", "f32")  # bf16 step: BatchNorm finalize folded into consumers
         # an event record costs the chain ~6 us (the next kernel waits for the barrier packet): the weight gradients of
         # several blocks can share one record, at the price of starting up to that many blocks later
         e = os.environ.get("MSL_WGRAD_RECORD_AT")
@@ -550,8 +554,16 @@ class Engine:
             D, H, W = pl.dims[f]
             off += D * H * W * m.boxes_per_location
         pl.P = off
-        if need_grad:  # the training step runs its head convolutions on the fp32 kernels (faster at these sizes)
+        pl.f32_heads = need_grad or self.bf16_heads != "bf16"
+        if pl.f32_heads:  # head convolutions on the fp32 kernels (faster at these sizes; the training step always)
             pl.fpad = {f: torch.zeros((N, specs[f]["cout"]) + tuple(d + 2 for d in pl.dims[f]), **f32) for f in pl.feat_ids}
+            if not need_grad:
+                pl.Wf, pl.Wb, pl.head_ws = {}, {}, {}
+                for f in pl.feat_ids:
+                    C = specs[f]["cout"]
+                    ne = L.msl_head_packed_weight_elems(C, ncls)
+                    pl.Wf[f], pl.Wb[f] = torch.empty(ne, **f32), torch.empty(ne, **f32)
+                    pl.head_ws[f] = torch.empty(max(L.msl_head_fwd_workspace_bytes(N, C, *pl.dims[f], ncls) // 4, 1), **f32)
         else:
             pl.fpad_cl = {f: torch.zeros((N,) + tuple(d + 2 for d in pl.dims[f]) + (specs[f]["cout"],), **bf) for f in pl.feat_ids}
             pl.Wp = {f: torch.empty(L.msl_head_packed_weight_bf16_elems(specs[f]["cout"]), **bf) for f in pl.feat_ids}
@@ -629,7 +641,7 @@ class Engine:
             for i in range(1, len(specs)):
                 every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], 1, 1.0), (feats[i].bn2, pl.bn_y[i], pl.part_y[i], 1, 1.0)]
             self._finalize_all(pl, every, st, eval_mode=True)
-        if need_grad:  # fp32 fragment copies for the head bwd-data kernel
+        if pl.f32_heads:  # MFMA-fragment copies of the head weights (forward and, in training, bwd-data)
             self._pack_head_weights(pl, st)
         part = (lambda t: ptr(t)) if training else (lambda t: None)
         L = _lib.load()
@@ -673,7 +685,7 @@ class Engine:
                         ptr(blk.conv2.weight), ptr(pl.y[i]), part(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
             if training and i in pl.feat_ids:  # the materialisation below reads the vectors
                 self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
-            if i in pl.feat_ids and need_grad:
+            if i in pl.feat_ids and pl.f32_heads:
                 self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16_pad32", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
                         ptr(pl.bn_y[i][1]), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
                 if want_features:

@@ -501,6 +501,22 @@ def test_bf16_inference_against_the_fp32_oracle(size, n):
         assert hit >= 0.9 * len(ob[i])
 
 
+def test_bf16_inference_with_the_bf16_head_kernel(monkeypatch):
+    """MSL_BF16_HEADS=bf16 keeps the head convolutions on the bf16 MFMA kernel (channels-last bf16 feature copy) instead of
+    the default fp32 head kernels: same tolerances against the fp32 oracle."""
+    monkeypatch.setenv("MSL_BF16_HEADS", "bf16")
+    size, n = (64, 64, 64), 2
+    m, om = _models(size)
+    assert m._engine.bf16_heads == "bf16"
+    x = detinit.make_volume_batch(9, n, 1, size)
+    with torch.no_grad():
+        ol, osc = om(x)
+        m.compute_dtype = "bf16"
+        bl, bs = (t.clone() for t in m(x.to(DEV)))
+    assert float((bl.cpu() - ol).abs().max() / ol.abs().max()) <= 3e-2
+    assert float((bs.cpu() - osc).abs().max() / osc.abs().max()) <= 3e-2
+
+
 def test_bf16_predict_step_replays():
     m, _ = _models((64, 64, 64))
     m.compute_dtype = "bf16"
