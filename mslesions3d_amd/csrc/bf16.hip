@@ -230,7 +230,7 @@ __global__ __launch_bounds__(256) void pw_fwd_bf16_kernel(const u16* __restrict_
   }
 }
 
-// ---- pointwise, pipelined form (S % 64 == 0, K % BK == 0) -----------------------------------------------------------------
+// ---- pointwise, pipelined form (S % 8 == 0, K % BK == 0) ------------------------------------------------------------------
 // Same GEMM and tile (64 rows x 64 positions, 4 waves = 2 x 2 tiles of 32 x 32) as pw_fwd_bf16_kernel, restructured around
 // what made that kernel slow (MFMA-busy 0.5 %): (1) the activation chunk keeps its memory orientation in LDS - rows = k,
 // 64 positions + pad per row, written with ONE 16-byte store per thread and group - and the MFMA operand (8 consecutive k
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void pw_bf16_tr_kernel(const u16* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, wm = wv >> 1, wn = wv & 1;
   const int r = lane & 31, h = lane >> 5;
   const int n = blockIdx.z, m0 = blockIdx.y * PT_BM;
-  const int tiles_img = S / PT_BN, tile0 = blockIdx.x * tiles_per_wg;
+  const int tiles_img = (S + PT_BN - 1) / PT_BN, tile0 = blockIdx.x * tiles_per_wg;  // the last tile may be partial (S % 8 == 0)
   const int ntiles = min(tiles_per_wg, tiles_img - tile0), nk = K / BK, total = ntiles * nk;
   const u16* Zn = Z + (size_t)n * K * S;
   u16* Yn = Y + (size_t)n * M * S;
@@ -295,7 +295,8 @@ __global__ __launch_bounds__(256) void pw_bf16_tr_kernel(const u16* __restrict__
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       const int idx = tid + 256 * j, krow = idx >> 3, c8 = (idx & 7) * 8;
-      xr[j] = *reinterpret_cast<const u16x8*>(Zn + (size_t)(k0 + krow) * S + s0 + c8);
+      const bool in = s0 + c8 < S;  // whole 8-column groups are inside or outside
+      xr[j] = *reinterpret_cast<const u16x8*>(Zn + (size_t)(k0 + krow) * S + (in ? s0 + c8 : 0));
     }
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
@@ -326,6 +327,7 @@ __global__ __launch_bounds__(256) void pw_bf16_tr_kernel(const u16* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = msl::f2bf(msl::act(msl::bf2f(o[e]), sc, sh));
       }
+      if ((tile0 + t) * PT_BN + c8 >= S) o = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};  // columns past the map: exact zeros
       *reinterpret_cast<u16x8*>(&Xs[krow * PT_RS + c8]) = o;
     }
 #pragma unroll
@@ -362,7 +364,7 @@ __global__ __launch_bounds__(256) void pw_bf16_tr_kernel(const u16* __restrict__
       for (int i = 0; i < 16; ++i) {
         const int row = m0 + wm * 32 + (i & 3) + 8 * (i >> 2) + 4 * h;
         const float v = acc[i];
-        if (row < M) Yn[(size_t)row * S + col] = msl::f2bf(v);
+        if (row < M && col < S) Yn[(size_t)row * S + col] = msl::f2bf(v);
         if (STATS) {
           const float sm = msl::half32_sum(v), q = msl::half32_sum(v * v);
           if (r == msl::HALF32_SUM_LANE && row < M && partials) {
@@ -376,15 +378,15 @@ __global__ __launch_bounds__(256) void pw_bf16_tr_kernel(const u16* __restrict__
   }
 }
 
-// the pipelined transposed-read kernel takes whole 64-position tiles and K in whole chunks (MSL_BF16_PW_TR=0: never)
+// the pipelined transposed-read kernel takes maps of whole 8-position groups and K in whole chunks (MSL_BF16_PW_TR=0: never)
 static bool pw_tr_ok(int M, int K, int S) {
   static const int on = getenv("MSL_BF16_PW_TR") ? atoi(getenv("MSL_BF16_PW_TR")) : 1;
-  return on && S % PT_BN == 0 && K % 32 == 0 && K <= PB_MAXK && M % 8 == 0;
+  return on && S % 8 == 0 && K % 32 == 0 && K <= PB_MAXK && M % 8 == 0;
 }
 template <bool STATS, bool TRANS_W>
 static void pw_tr_launch(const u16* z, const float* in_scale, const float* in_shift, const float* w, u16* y, double* partials,
                          int N, int M, int K, int S, const msl::BnFold& fold, hipStream_t st) {
-  const int tiles_img = S / PT_BN, mtiles = msl::cdiv(M, PT_BM);
+  const int tiles_img = msl::cdiv(S, PT_BN), mtiles = msl::cdiv(M, PT_BM);
   // several position tiles per workgroup once the launch has more than ~2 workgroups per CU (block 1: 2048 tiles)
   const int T = std::max(1, std::min(std::min(4, tiles_img), (tiles_img * mtiles * N) / 512));
   dim3 grid(msl::cdiv(tiles_img, T), mtiles, N);

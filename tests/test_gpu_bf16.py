@@ -71,7 +71,7 @@ def test_dw_fwd_bf16(N, C, dims, stride, affine):
                                           # whole 64-position tiles: the pipelined transposed-read kernel (K chunks of 32 / 64 /
                                           # 128, several position tiles per workgroup, row counts that are no multiple of 64)
                                           (4, 32, 64, 32768), (2, 64, 128, 4096), (1, 32, 96, 256), (2, 96, 160, 128),
-                                          (4, 512, 512, 64), (3, 256, 40, 192)])
+                                          (4, 512, 512, 64), (3, 256, 40, 192), (2, 256, 512, 216), (1, 64, 64, 8), (2, 128, 96, 1000)])
 def test_pw_fwd_bf16(N, Cin, Cout, S):
     """Pointwise GEMM on v_mfma_f32_32x32x16_bf16: operands rounded to bf16 (activation after its fp32 affine + ReLU,
     weights), fp32 accumulation -> equals the fp32 product of the rounded operands up to summation order."""
@@ -186,7 +186,7 @@ def b16(t):
                                           (3, 64, 128, 4096), (1, 32, 64, 32768), (2, 128, 128, 4096),
                                           # ragged position counts: the plain one-slab weight-gradient kernel
                                           (2, 512, 512, 8), (1, 256, 512, 27), (2, 32, 64, 100),
-                                          (2, 96, 160, 128), (1, 40, 256, 192)])
+                                          (2, 96, 160, 128), (1, 40, 256, 192), (2, 256, 512, 216), (2, 128, 96, 1000)])
 def test_pw_bwd_bf16(N, Cin, Cout, S):
     """Pointwise bwd-data (W^T . dY on the bf16 MFMA) and weight gradient (positions as the MFMA K axis, fp32 slabs +
     batched reduction) against fp64 products of the same bf16-rounded operands."""
