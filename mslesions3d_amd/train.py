@@ -49,6 +49,8 @@ def build_parser():
     p.add_argument('--hard_negative_mining', action='store_true')
     p.add_argument('--smooth_l1', action='store_true')
     p.add_argument('--focal_loss', action='store_true')
+    # build-side extension (the reference trains in fp32): activations and activation gradients stored as bf16
+    p.add_argument('--dtype', choices=["f32", "bf16"], default="f32")
     return p
 
 
@@ -80,6 +82,7 @@ def example(args):
                        focal_loss=args.focal_loss)
     model.init()
     model = model.to("cuda")
+    model.compute_dtype = args.dtype
     trainer = FusedTrainer(model)
     first_epoch = 0
     if args.checkpoint:

@@ -639,3 +639,27 @@ def test_bf16_fused_trainer_follows_the_fp32_trajectory():
     assert np.array_equal(runs["bf16"][0], runs["bf16-eager"][0])
     for a, b in zip(runs["bf16"][1], runs["bf16-eager"][1]):
         assert torch.equal(a, b)
+
+
+def test_bf16_train_and_predict_entry_points(tmp_path):
+    """train.py --dtype bf16 (2 epochs on generated 64^3 volumes, validation mAP included) and predict.py --dtype bf16 on the
+    checkpoint it wrote: the entry points of the bf16 configurations run end to end."""
+    import glob
+    import json
+    from mslesions3d_amd import datasets as DS
+    from mslesions3d_amd import predict as P
+    from mslesions3d_amd import train as T
+    DS.generate_artificial_dataset(str(tmp_path / "data"), "toy64", num_images=10, image_size=(64, 64, 64))
+    args = T.build_parser().parse_args(["-d", str(tmp_path / "data"), "-dn", "toy64", "-b", "2", "-me", "2", "-ld",
+                                        str(tmp_path / "logs"), "-en", "run", "--dtype", "bf16"])
+    model = T.example(args)
+    assert model.compute_dtype == "bf16" and model.global_step == 8
+    lines = [json.loads(l) for l in open(tmp_path / "logs" / "run" / "metrics.jsonl")]
+    losses = [l["total_loss/training"] for l in lines if "total_loss/training" in l]
+    assert len(losses) == 8 and all(v == v and v < 1e6 for v in losses)
+    ckpts = sorted(glob.glob(str(tmp_path / "logs" / "run" / "*.ckpt")))
+    assert ckpts
+    pargs = P.build_parser().parse_args(["-d", str(tmp_path / "data"), "-dn", "toy64", "-m", ckpts[0], "-o", str(tmp_path / "pred"),
+                                         "-ps", "test", "-sc", "0.3", "--dtype", "bf16"])
+    metrics = P.predict_example(pargs)
+    assert set(metrics) == {"0.5", "0.1"}
