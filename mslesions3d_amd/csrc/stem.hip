@@ -300,6 +300,146 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Stem forward, row-staged form (stride 2 along W, W % 4 == 0, OW % 32 == 0, Cin <= 2).  The register-fed kernel above is
+// bound by vector-memory INSTRUCTION issue: 14 stride-2 dword gathers per 32-column tile (17.6 of its 45 us at 128^3 x 4).
+// Here a wave fetches the 9 * Cin input rows of a 64-column chunk CONTIGUOUSLY - 33 lanes x 16 bytes per row, columns
+// [2*ow0 - 4, 2*ow0 + 128) - parks them in its own LDS region (two buffers; the next chunk's rows are in flight during
+// this chunk's MFMAs and stores) and reads every im2col operand from LDS (stride-2 ds_read_b32: 2-way bank conflicts, cheap).
+// 9 contiguous loads per 64 columns instead of 28 gathers; rows / columns outside the volume are zeros written to LDS, so
+// there is no border path at all.  Same tile walk, statistics and partial layout as stem_fwd_mfma_kernel.
+constexpr int SFR_RP = 136;  // LDS row pitch in floats (132 used; 136 % 32 == 8)
+template <int CIN, bool BF16OUT>
+__global__ __launch_bounds__(256) void stem_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            void* __restrict__ y, double* __restrict__ partials, int D, int H,
+                                                            int W, int OD, int OH, int OW, int sd, int sh, int chunks_per_row,
+                                                            int chunks_per_n, int iters) {
+  constexpr int K = CIN * 27, KS = (K + 1) / 2, NR = CIN * 9;
+  extern __shared__ __align__(16) float rows_all[];  // [4 waves][2][NR * SFR_RP]
+  __shared__ float red[4][2][32];
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int h = lane >> 5, c = lane & 31;
+  const int n = blockIdx.y;
+  const int OS = OD * OH * OW;
+  const float* xn = x + (size_t)n * CIN * D * H * W;
+  constexpr int EB = BF16OUT ? 2 : 4;
+  char* yn = (char*)y + (size_t)n * STEM_COUT * OS * EB;
+  float* myrows = rows_all + (size_t)wv * 2 * NR * SFR_RP;
+
+  float wa[KS];
+  int ldsoff[KS];  // LDS element of the lane's tap kk for output column 0 of the chunk's first half
+#pragma unroll
+  for (int kk = 0; kk < KS; ++kk) {
+    const int k = 2 * kk + h;
+    const bool vk = k < K;
+    const int ci = k / 27, t = k % 27, kd = t / 9, kh = (t / 3) % 3, kw = t % 3;
+    wa[kk] = vk ? w[c * K + (vk ? k : 0)] : 0.f;
+    ldsoff[kk] = (vk ? (ci * 9 + kd * 3 + kh) * SFR_RP + kw : 0) + 3 + 2 * c;
+  }
+  float ssum[16], qsum[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) ssum[r] = qsum[r] = 0.f;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)msl::uniform_base(xn), 0, (int)((unsigned)CIN * D * H * W * 4u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)msl::uniform_base(yn), 0, (int)((unsigned)STEM_COUT * OS * (unsigned)EB), 0x00020000);
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  const int lblock = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int chunk0 = (lblock * 4 + wv) * iters;
+  struct Chunk {
+    bool live;
+    int od, oh, ow0;  // wave-uniform
+  };
+  auto chunk_at = [&](int it) {
+    Chunk q;
+    const int ch = chunk0 + it;
+    q.live = it < iters && ch < chunks_per_n;
+    const int cc = __builtin_amdgcn_readfirstlane(q.live ? ch : 0);
+    const int seg = cc % chunks_per_row, r0 = cc / chunks_per_row;
+    q.ow0 = seg * 64;
+    q.oh = r0 % OH;
+    q.od = r0 / OH;
+    return q;
+  };
+  // the rows of a chunk: lane l < 33 holds floats [4l, 4l + 4) of every row (columns 2*ow0 - 4 + 4l ..)
+  auto issue = [&](const Chunk& q, u32x4 (&rr)[NR]) {
+    const int id0 = q.od * sd - 1, ih0 = q.oh * sh - 1, col0 = 2 * q.ow0 - 4;
+    const bool lane_in = lane < 33 && !(q.ow0 == 0 && lane == 0);  // columns -4 .. -1 of the first chunk: padding
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int ci = r / 9, kd = (r % 9) / 3, kh = r % 3;
+      const int id = id0 + kd, ih = ih0 + kh;
+      const bool row_in = q.live && id >= 0 && id < D && ih >= 0 && ih < H;  // wave-uniform
+      rr[r] = (u32x4){0u, 0u, 0u, 0u};
+      if (row_in) {
+        const int off = (((ci * D + id) * H + ih) * W + col0 + 4 * lane) * 4;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rx, lane_in ? off : 0, 0, 0);
+        if (lane_in) rr[r] = v;
+      }
+    }
+  };
+  auto park = [&](const u32x4 (&rr)[NR], float* buf) {
+    if (lane < 33) {
+#pragma unroll
+      for (int r = 0; r < NR; ++r) *reinterpret_cast<u32x4*>(buf + r * SFR_RP + 4 * lane) = rr[r];
+    }
+  };
+  auto store_out = [&](float v, int voff, int soff) {
+    if (BF16OUT) __builtin_amdgcn_raw_buffer_store_b16((short)msl::f2bf(v), ry, voff, soff, 0);
+    else __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), ry, voff, soff, 0);
+  };
+  const int loff4 = (4 * h * OS + c) * EB;  // per lane, bytes: rows 4h.., column c
+  u32x4 rr[NR];
+  Chunk cur = chunk_at(0);
+  issue(cur, rr);
+  for (int it = 0; it < iters; ++it) {
+    if (!cur.live) break;  // wave-uniform; a wave's chunks are consecutive
+    float* buf = myrows + (it & 1) * NR * SFR_RP;
+    park(rr, buf);  // (a wave's LDS operations execute in order: no barrier; the other buffer is still being read by nobody)
+    const Chunk nxt = chunk_at(it + 1);
+    issue(nxt, rr);  // in flight during this chunk's MFMAs and stores
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int owt = cur.ow0 + 32 * half;
+      if (owt >= OW) continue;  // wave-uniform (OW % 32 == 0: a tile is inside or outside)
+      f32x16 acc = {0};
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[kk], buf[ldsoff[kk] + 64 * half], acc, 0, 0, 0);
+      const int yoff = __builtin_amdgcn_readfirstlane(((cur.od * OH + cur.oh) * OW + owt) * EB);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) store_out(acc[r], loff4, yoff + ((r & 3) + 8 * (r >> 2)) * OS * EB);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = acc[r];
+        ssum[r] += v;
+        qsum[r] = fmaf(v, v, qsum[r]);
+      }
+    }
+    cur = nxt;
+  }
+  if (partials) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float s = msl::half32_sum(ssum[r]), q = msl::half32_sum(qsum[r]);
+      if (c == msl::HALF32_SUM_LANE) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        red[wv][0][row] = s;
+        red[wv][1][row] = q;
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+      const int ch = threadIdx.x;
+      const double s = ((double)red[0][0][ch] + (double)red[1][0][ch]) + ((double)red[2][0][ch] + (double)red[3][0][ch]);
+      const double q = ((double)red[0][1][ch] + (double)red[1][1][ch]) + ((double)red[2][1][ch] + (double)red[3][1][ch]);
+      const int NP = gridDim.x * gridDim.y, p = n * gridDim.x + blockIdx.x;
+      partials[(size_t)ch * NP + p] = s;
+      partials[((size_t)STEM_COUT + ch) * NP + p] = q;
+    }
+  }
+}
+
 constexpr int STEM_FWD_BLOCKS_PER_IMAGE = 256;
 
 // ---------------------------------------------------------------------------------------------
@@ -734,6 +874,26 @@ static int stem_fwd_impl(const float* x, const float* w, void* y, double* partia
   const int iters = msl::cdiv(chunks_per_n, nb * 4);
   dim3 grid(nb, N);
   hipStream_t st = (hipStream_t)stream;
+  static const int rows_on = getenv("MSL_STEM_FWD_ROWS") ? atoi(getenv("MSL_STEM_FWD_ROWS")) : 1;
+  if (rows_on && sw == 2 && W % 4 == 0 && OW % 32 == 0 && Cin <= 2) {
+    // row-staged form (contiguous 16-byte row loads, operands from LDS)
+    const size_t lds = (size_t)4 * 2 * Cin * 9 * SFR_RP * sizeof(float);
+#define MSL_STEM_FR(CI, B_)                                                                                             \
+  do {                                                                                                                  \
+    if (lds > 64 * 1024) {                                                                                              \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_fwd_rows_kernel<CI, B_>),                 \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+      if (e_ != hipSuccess) return (int)e_;                                                                             \
+    }                                                                                                                   \
+    hipLaunchKernelGGL((stem_fwd_rows_kernel<CI, B_>), grid, dim3(256), lds, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, \
+                       sh, chunks_per_row, chunks_per_n, iters);                                                        \
+  } while (0)
+    if (Cin == 1) { if (bf16_out) MSL_STEM_FR(1, true); else MSL_STEM_FR(1, false); }
+    else { if (bf16_out) MSL_STEM_FR(2, true); else MSL_STEM_FR(2, false); }
+#undef MSL_STEM_FR
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
 #define MSL_STEM_FW(CI)                                                                                                 \
   do {                                                                                                                  \
     if (bf16_out)                                                                                                       \

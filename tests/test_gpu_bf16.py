@@ -23,7 +23,8 @@ def bfr(t):
     return t.to(torch.bfloat16).float()
 
 
-@pytest.mark.parametrize("cin,dims,stride", [(1, (16, 16, 16), (2, 2, 2)), (2, (10, 12, 20), (1, 2, 2)), (1, (9, 11, 13), (2, 2, 2))])
+@pytest.mark.parametrize("cin,dims,stride", [(1, (16, 16, 16), (2, 2, 2)), (2, (10, 12, 20), (1, 2, 2)), (1, (9, 11, 13), (2, 2, 2)),
+                                             (1, (6, 10, 128), (2, 2, 2)), (2, (5, 8, 192), (1, 2, 2))])
 def test_stem_fwd_bf16(cin, dims, stride):
     L = _lib.load()
     N = 2

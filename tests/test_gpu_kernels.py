@@ -59,7 +59,11 @@ def affine_act(x, sc, sh):
 
 # ------------------------------------------------------------------------------------------------- stem
 @pytest.mark.parametrize("cin,dims,stride", [(1, (16, 16, 16), (2, 2, 2)), (2, (10, 12, 20), (1, 2, 2)),
-                                             (1, (9, 11, 13), (2, 2, 2)), (3, (8, 8, 8), (2, 2, 2))])
+                                             (1, (9, 11, 13), (2, 2, 2)), (3, (8, 8, 8), (2, 2, 2)),
+                                             # W % 4 == 0, OW % 32 == 0, Cin <= 2: the row-staged kernel (whole and half
+                                             # chunks, first / last planes and rows, depth stride 1, two input channels)
+                                             (1, (8, 12, 64), (2, 2, 2)), (1, (6, 10, 128), (2, 2, 2)), (2, (5, 8, 192), (1, 2, 2)),
+                                             (1, (3, 3, 256), (2, 2, 2)), (2, (7, 9, 320), (2, 2, 2))])
 def test_stem_fwd(cin, dims, stride):
     L = _lib.load()
     N = 2
