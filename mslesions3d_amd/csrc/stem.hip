@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void stem_fwd_mfma_kernel(const float* __restr
 // there is no border path at all.  Same tile walk, statistics and partial layout as stem_fwd_mfma_kernel.
 constexpr int SFR_RP = 136;  // LDS row pitch in floats (132 used; 136 % 32 == 8)
 template <int CIN, bool BF16OUT>
-__global__ __launch_bounds__(256) void stem_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(CIN == 1 ? 4 : 2))) void stem_fwd_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             void* __restrict__ y, double* __restrict__ partials, int D, int H,
                                                             int W, int OD, int OH, int OW, int sd, int sh, int chunks_per_row,
                                                             int chunks_per_n, int iters) {
