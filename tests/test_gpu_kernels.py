@@ -477,7 +477,10 @@ def test_bn_forward_backward():
                                            # block counts per workgroup in the weight gradient, D != W
                                            (2, 128, (16, 16, 16), 2), (4, 256, (8, 8, 8), 2), (4, 512, (4, 4, 4), 2),
                                            (1, 16, (16, 16, 16), 2), (3, 48, (8, 8, 8), 2), (1, 32, (8, 4, 4), 2),
-                                           (5, 16, (12, 8, 8), 2), (1, 32, (16, 16, 16), 3)])
+                                           (5, 16, (12, 8, 8), 2), (1, 32, (16, 16, 16), 3),
+                                           # the 192^3 inference maps (register-fed kernels; an LDS geometry with 48-position blocks was measured no faster)
+                                           (2, 128, (24, 24, 24), 2), (2, 256, (12, 12, 12), 2), (1, 16, (12, 12, 12), 2),
+                                           (1, 32, (5, 24, 24), 2)])
 def test_heads_fwd_bwd(N, C, dims, ncls):
     L = _lib.load()
     a = torch.relu(rnd(N, C, *dims, seed=30)).requires_grad_(True)
@@ -519,8 +522,10 @@ def test_heads_fwd_bwd(N, C, dims, ncls):
     glw, gcw = torch.full(lw.shape, float("nan"), device=DEV), torch.full(cw.shape, float("nan"), device=DEV)
     glb, gcb = torch.empty(12, device=DEV), torch.empty(2 * ncls, device=DEV)
     _lib.call("msl_head_conv_bwd_weight", ptr(dO), ptr(pad), ptr(glw), ptr(gcw), ptr(glb), ptr(gcb), ptr(ws), N, C, *dims, ncls, st())
-    close(glw, lw.grad, 1e-4, 1e-4, "head dW loc")
-    close(gcw, cw.grad, 1e-4, 1e-4, "head dW cls")
+    # sums over N * S products (27 648 at 24^3 x 2): the absolute error scales with the largest gradient element
+    atol_w = max(1e-4, 2e-6 * float(max(lw.grad.abs().max(), cw.grad.abs().max())))
+    close(glw, lw.grad, 1e-4, atol_w, "head dW loc")
+    close(gcw, cw.grad, 1e-4, atol_w, "head dW cls")
     close(glb, lb.grad, 1e-4, 1e-4, "head db loc")
     close(gcb, cb.grad, 1e-4, 1e-4, "head db cls")
 
