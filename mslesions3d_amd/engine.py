@@ -68,11 +68,29 @@ class ParamArena:
                         self.is_bias[off:off + n] = 1
                 off += n
         self.params = {name: p for name, p in ordered}
+        # ownership fingerprint (see owns): every parameter slot and every sub-module slot of the model at build time
+        self._model = model
+        self._slots = []
+        for prefix, mod in model.named_modules():
+            for key, q in mod._parameters.items():
+                if q is not None:
+                    name = f"{prefix}.{key}" if prefix else key
+                    self._slots.append((mod._parameters, key, q, self.views[name].data_ptr()))
+        self._mods = [(parent._modules, name, child) for parent in model.modules()
+                      for name, child in parent._modules.items() if child is not None]
 
     def owns(self, model):
-        for name, p in model.named_parameters():
-            v = self.views.get(name)
-            if v is None or p.data_ptr() != v.data_ptr():
+        """Are the model's parameters still the views of this arena?  Called on every step / batch, so it must not walk
+        ``named_parameters()`` (~100 us of Python): it re-checks the slots recorded at build time - a parameter object
+        replaced in its module, a parameter whose storage moved (``.to()``, ``p.data = ...``), a sub-module swapped."""
+        if model is not self._model:
+            return False
+        for d, k, q, ptr in self._slots:
+            cur = d.get(k)
+            if cur is not q or cur.data_ptr() != ptr:
+                return False
+        for d, k, child in self._mods:
+            if d.get(k) is not child:
                 return False
         return True
 
@@ -1252,7 +1270,10 @@ class Engine:
 
     def check_nan(self, pl):
         """One host sync: raise like ssd3d.py:258-261 if the forward produced NaN."""
-        flag = int(pl.nan_flag.item())
+        self.raise_on_nan_flag(int(pl.nan_flag.item()))
+
+    @staticmethod
+    def raise_on_nan_flag(flag):
         if flag & 2:
             raise Exception("Oh no not this NaN error again... (forward SSD), CLASSES_SCORES is nan!")
         if flag & 1:

@@ -401,7 +401,10 @@ class LSSD3D(nn.Module):
                       os=torch.empty((N, top_k), dtype=f32, device=dev),
                       ol=torch.empty((N, top_k), dtype=i64, device=dev),
                       op=torch.empty((N, top_k), dtype=i64, device=dev),
-                      oc=torch.zeros(N, dtype=i32, device=dev))
+                      oc=torch.zeros(N, dtype=i32, device=dev),
+                      # pinned landing zone of the per-image detection counts (+ one slot for a NaN flag): filled by async
+                      # copies, read after ONE stream synchronisation (a blocking 4-byte device-to-host copy costs 50-100 us)
+                      host=torch.empty(N + 1, dtype=i32).pin_memory())
             self._det_ws[key] = ws
         return ws
 
@@ -429,14 +432,25 @@ class LSSD3D(nn.Module):
                   ptr(w["os"]), ptr(w["ol"]), ptr(w["op"]), ptr(w["oc"]), _stream())
 
     @staticmethod
-    def _detect_collect(w, N, return_prior_index=False):
-        counts = w["oc"].tolist()  # the only host sync
-        boxes = [w["ob"][i, :counts[i]].clone() for i in range(N)]
-        labels = [w["ol"][i, :counts[i]].clone() for i in range(N)]
-        dscores = [w["os"][i, :counts[i]].clone() for i in range(N)]
-        if return_prior_index:
-            return boxes, labels, dscores, [w["op"][i, :counts[i]].clone() for i in range(N)]
-        return boxes, labels, dscores
+    def _detect_collect(w, N, return_prior_index=False, nan_flag=None):
+        """Detections out of the workspace: one clone per output buffer (the workspace is reused by the next batch), the
+        counts (and, if given, the forward pass's NaN flag) through pinned memory, ONE host synchronisation.  With
+        ``nan_flag`` the flag's value is returned as the last element."""
+        host = w["host"]
+        host[:N].copy_(w["oc"], non_blocking=True)
+        if nan_flag is not None:
+            host[N:].copy_(nan_flag, non_blocking=True)
+        ob, ol, os_ = w["ob"].clone(), w["ol"].clone(), w["os"].clone()
+        op = w["op"].clone() if return_prior_index else None
+        torch.cuda.current_stream(w["oc"].device).synchronize()  # the only host sync
+        counts = host[:N].tolist()
+        boxes = [ob[i, :counts[i]] for i in range(N)]
+        labels = [ol[i, :counts[i]] for i in range(N)]
+        dscores = [os_[i, :counts[i]] for i in range(N)]
+        out = (boxes, labels, dscores, [op[i, :counts[i]] for i in range(N)]) if return_prior_index else (boxes, labels, dscores)
+        if nan_flag is not None:
+            return out + (int(host[N]),)
+        return out
 
     # -- steps ------------------------------------------------------------------------------------------------
     def _gt_warnings(self, gt_boxes, subjects):
@@ -519,12 +533,13 @@ class LSSD3D(nn.Module):
         through the executor and records its C-ABI calls on a persistent input buffer; later batches are copied into that
         buffer and the launch program is replayed natively (same kernels, same arguments).  One host sync per batch."""
         dev = self.device
-        x = img.to(dev, non_blocking=True).contiguous().float()
+        x = img
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.device == dev):  # (each no-op costs ~2 us)
+            x = img.to(dev, non_blocking=True).contiguous().float()
         self._ensure_device_state(dev)
         eng = self._engine
         eng.ensure_arena(dev)
-        key = (tuple(x.shape), _stream(), float(self.min_score), float(self.max_overlap), int(self.top_k), id(eng.arena),
-               self.compute_dtype)
+        key = (x.shape, _stream(), self.min_score, self.max_overlap, self.top_k, id(eng.arena), self.compute_dtype)
         ent = self._pred_programs.get(key)
         if ent is None:
             buf = torch.empty_like(x)
@@ -541,9 +556,9 @@ class LSSD3D(nn.Module):
         else:
             ent["buf"].copy_(x)
             _lib.replay_native(ent["compiled"], None)
-        out = self._detect_collect(ent["ws"], x.size(0))
-        eng.check_nan(ent["plan"])  # the queue is already drained: no second wait
-        return out
+        *out, flag = self._detect_collect(ent["ws"], x.size(0), nan_flag=ent["plan"].nan_flag)
+        eng.raise_on_nan_flag(flag)  # (the forward pass's NaN flag came over with the detection counts)
+        return tuple(out)
 
     def configure_optimizers(self):
         """ssd3d.py:704-722: Adam(weight_decay 5e-4), '.bias' parameters at 2*lr, cosine annealing T_max=40."""

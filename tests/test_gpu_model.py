@@ -279,6 +279,54 @@ def test_relu_mask_agreement_with_the_oracle(size, n):
     print(f"[relu masks {size[0]}^3 x{n}] largest per-layer disagreement with the oracle: {worst:.2e}")
 
 
+def test_parameter_arena_notices_replaced_parameters():
+    """The flat parameter arena is re-built when a parameter stops being its view: a parameter object replaced in its
+    module, a storage swapped through ``.data``, a whole sub-module replaced.  (The per-step check is a slot fingerprint, not a
+    walk over ``named_parameters()``.)"""
+    import copy
+    size, n = (64, 64, 64), 2
+    x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
+    m = hip_model(1, size).eval()
+
+    def fresh_output(state):
+        f = hip_model(1, size).eval()
+        f.load_state_dict(state)
+        with torch.no_grad():
+            return [t.clone() for t in f(x)]
+
+    with torch.no_grad():
+        base = [t.clone() for t in m(x)]
+        arena0 = m._engine.arena
+        # (a) a parameter object replaced
+        w = m.base.features[3].conv1.weight
+        m.base.features[3].conv1.weight = torch.nn.Parameter(w.detach() * 1.5)
+        out = [t.clone() for t in m(x)]
+        assert m._engine.arena is not arena0 and not torch.equal(out[0], base[0])
+        ref = fresh_output(copy.deepcopy(m.state_dict()))
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+        # (b) a storage swapped through .data
+        arena1 = m._engine.arena
+        p = m.pred_convs.loc_convs[0].bias
+        p.data = p.data.clone() + 0.25
+        out = [t.clone() for t in m(x)]
+        assert m._engine.arena is not arena1
+        ref = fresh_output(copy.deepcopy(m.state_dict()))
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+        # (c) a sub-module swapped
+        arena2 = m._engine.arena
+        blk = copy.deepcopy(m.base.features[6])
+        blk.conv2.weight.data.mul_(0.5)
+        m.base.features[6] = blk
+        out = [t.clone() for t in m(x)]
+        assert m._engine.arena is not arena2
+        ref = fresh_output(copy.deepcopy(m.state_dict()))
+        assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+        # (d) nothing changed: the arena stays
+        arena3 = m._engine.arena
+        m(x)
+        assert m._engine.arena is arena3
+
+
 def test_two_adam_steps_golden():
     """Two optimisation steps through the reference-shaped API (training_step inside the optimiser closure, as
     Lightning's automatic optimisation runs ssd3d.py:467-531: the scheduler steps before the update) against the
