@@ -533,17 +533,15 @@ class LSSD3D(nn.Module):
         through the executor and records its C-ABI calls on a persistent input buffer; later batches are copied into that
         buffer and the launch program is replayed natively (same kernels, same arguments).  One host sync per batch."""
         dev = self.device
-        x = img
-        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.device == dev):  # (each no-op costs ~2 us)
-            x = img.to(dev, non_blocking=True).contiguous().float()
+        x = img  # a host tensor goes straight into the staging buffer below (one host-to-device copy, no device-side second copy)
         self._ensure_device_state(dev)
         eng = self._engine
         eng.ensure_arena(dev)
         key = (x.shape, _stream(), self.min_score, self.max_overlap, self.top_k, id(eng.arena), self.compute_dtype)
         ent = self._pred_programs.get(key)
         if ent is None:
-            buf = torch.empty_like(x)
-            buf.copy_(x)
+            buf = torch.empty(x.shape, dtype=torch.float32, device=dev)
+            buf.copy_(x, non_blocking=True)
             _lib.start_recording()
             try:
                 locs, scores = eng.forward(buf, training=False, need_grad=False)
@@ -554,7 +552,7 @@ class LSSD3D(nn.Module):
             ent = self._pred_programs[key] = {"buf": buf, "ws": w, "plan": eng.plan_for(buf, False),
                                               "compiled": _lib.compile_program(prog, set())}
         else:
-            ent["buf"].copy_(x)
+            ent["buf"].copy_(x, non_blocking=True)
             _lib.replay_native(ent["compiled"], None)
         *out, flag = self._detect_collect(ent["ws"], x.size(0), nan_flag=ent["plan"].nan_flag)
         eng.raise_on_nan_flag(flag)  # (the forward pass's NaN flag came over with the detection counts)
