@@ -777,3 +777,43 @@ def test_data_parallel_two_ranks_share_one_gpu():
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 4 and out["value"] > 0
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_bench_line_contract(dtype):
+    """bench.py prints ONE JSON line with the fields the driver reads: metric / value / unit / n_gpus / steps / warmup /
+    ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a roofline object (bound, achieved,
+    peak, unit, frac, traffic + its source, the rocprof-based fraction with its profile tag, the three accountings of the
+    seven-layer depthwise aggregate under fixed keys), a cpu_baseline object (value, unit, cores, kind, sample) and the
+    MSL_* knobs that were set."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSL_FOLD_NP_MAX="64")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-steps", "1", "--dtype", dtype],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "knobs"):
+        assert k in d, k
+    assert d["unit"] == "volumes/s" and d["n_gpus"] == 1 and d["steps"] == 12 and d["warmup"] == 3 and d["dtype"] == dtype
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - 4 * 12 / (d["ms_per_step"] * 12 * 1e-3)) <= 0.01 * d["value"]
+    r_ = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "frac_rocprof", "frac_basis", "kernel",
+              "algorithmic_bytes_per_launch", "avg_launch_us", "depthwise_fwd_all_layers"):
+        assert k in r_, k
+    assert r_["bound"] == "hbm" and r_["unit"] == "GB/s" and r_["peak"] == 8000.0
+    assert abs(r_["frac"] - r_["achieved"] / r_["peak"]) < 1e-3 and 0.05 < r_["frac"] < 1.0
+    assert r_["frac_rocprof"] is None or ("profile" in r_["frac_rocprof"] and r_["frac_rocprof"]["profile"].startswith("profiles/"))
+    agg = r_["depthwise_fwd_all_layers"]
+    assert {"in_step_event_pairs", "back_to_back", "rocprof_kernel_trace", "algorithmic_bytes"} <= set(agg)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "volumes/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert d["knobs"].get("MSL_FOLD_NP_MAX") == "64"
