@@ -831,6 +831,300 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused stem weight gradient, TILE-STAGED form (MODE 2 semantics; stride 2 on every axis, W == 128 -> OW == 64,
+// OH % 8 == 0, Cin <= 2): what the 128^3 training configurations run.
+// The wave-private kernel above gives a lane ONE output position: 5 dword loads per (position, channel), 4 of them the
+// dz slots of which 2.25 are live on average - 187 vector-memory instructions and 4 load->use round trips per 64
+// positions, 2 waves per SIMD: bound by instruction issue and latency at 2 TB/s.  Here a WORKGROUP owns a tile of 256
+// positions = 4 output rows (n, od, oh = p + 2*(4*g4 + r), r = 0..3) of ONE oh parity p, so the live (kd, kh) slot set
+// is uniform over the tile, and a lane owns FOUR consecutive positions ow = 4m .. 4m+3 of one row:
+//   * y: one 16-byte load per (lane, channel); dz: one 8-byte load (dz[2m], dz[2m+1]) per (lane, channel, slot), the
+//     third value dz[2m+2] is the next lane's first (DPP row_shl:1 inside the 16-lane row; the row end shifts in the
+//     zero the border needs) - 45 instead of 748 vector loads per 256 positions and wave;
+//   * produce phase: wave w rebuilds g = dwconv^T(dz) for channels 8w..8w+7, applies the folded BatchNorm backward and
+//     writes the rows [c][256] of the shared g tile (ds_write_b128); the 36*Cin input rows of the tile go to LDS as
+//     contiguous 16-byte row loads (pitch 131: the 27 taps of a position sit on distinct banks);
+//   * MFMA phase: wave w takes output row w of the tile (64 positions = 32 k-steps of v_mfma_f32_32x32x2_f32, M = 32
+//     channels, N = 27*Cin taps): the g operand comes as one ds_read_b128 per 4 k-steps (k-step s = 4q + j multiplies
+//     positions 8q + j and 8q + 4 + j), the im2col operand as one stride-2 ds_read_b32 per MFMA;
+//   * the next tile's loads are issued between the two phases and land during the MFMAs.
+// Same slab layout / reduction as stem_bwd_weight_kernel (one [32][32*NT] slab per workgroup).
+constexpr int SBT_LDA = 260;  // g-tile pitch in floats: rows 16-byte aligned and (pitch / 4) odd -> conflict-free ds_read_b128
+constexpr int SBT_RP = 131;   // input-row pitch (1 + 128 used); 131 % 32 == 3
+
+template <int CIN, bool BF16ACT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_bww_tile_kernel(const void* __restrict__ dzp, const void* __restrict__ yp,
+                                                            const float* __restrict__ x, float* __restrict__ slabs, int N,
+                                                            int D, int H, int OD, int OH, int tiles_total, int iters,
+                                                            const float* __restrict__ bnv, const float* __restrict__ w1p) {
+  constexpr unsigned ES = BF16ACT ? 2u : 4u;
+  constexpr int NT = (CIN * 27 + 31) / 32;
+  constexpr int W = 128, OW = 64, OW1 = 32;
+  constexpr int NROWS = 4 * CIN * 9;             // input rows of a tile
+  constexpr int NXL = (NROWS / 2 + 3) / 4;       // row-pair loads per wave and tile
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  extern __shared__ __align__(16) float lds[];
+  float* At = lds;                               // [32][SBT_LDA]
+  float* rows = lds + 32 * SBT_LDA;              // [NROWS][SBT_RP], row = (r * CIN + ci) * 9 + kd * 3 + kh
+  const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int r = lane >> 4, m = lane & 15, h = lane >> 5;
+  const int OD1 = (OD - 1) / 2 + 1, OH1 = OH >> 1;
+  const unsigned OS = (unsigned)OD * OH * OW, OS1 = (unsigned)OD1 * OH1 * OW1;
+  const int gpc = OH >> 3;                       // tiles per (n, od, parity)
+
+  int tapoff[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int k = nt * 32 + (lane & 31);
+    if (k < CIN * 27) {
+      const int ci = k / 27, t = k % 27;
+      tapoff[nt] = (ci * 9 + t / 3) * SBT_RP + (t % 3);
+    } else {
+      tapoff[nt] = 0;  // padding column of the GEMM: accumulates a value the reduction drops
+    }
+  }
+  f32x16 acc[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
+  for (int R = threadIdx.x; R < NROWS; R += 256) rows[R * SBT_RP] = 0.f;  // column iw = -1 of every row
+
+  const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)msl::uniform_base(yp), 0, (int)((unsigned)N * 32u * OS * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rdz = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)msl::uniform_base(dzp), 0, (int)((unsigned)N * 32u * OS1 * ES), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)msl::uniform_base(x), 0, (int)((unsigned)N * CIN * D * H * W * 4u), 0x00020000);
+
+  // the input rows this lane fetches: pair u of the wave = rows 2*(wv + 4u) + h, constant over the tiles
+  int xr_out[NXL], xr_ci[NXL], xr_kd[NXL], xr_kh[NXL], xr_row[NXL];
+  bool xr_valid[NXL];
+#pragma unroll
+  for (int u = 0; u < NXL; ++u) {
+    const int R = 2 * (wv + 4 * u) + h;
+    xr_valid[u] = R < NROWS;
+    const int Rc = xr_valid[u] ? R : 0;
+    xr_row[u] = Rc;
+    xr_out[u] = Rc / (CIN * 9);
+    const int rem = Rc % (CIN * 9);
+    xr_ci[u] = rem / 9;
+    xr_kd[u] = (rem % 9) / 3;
+    xr_kh[u] = rem % 3;
+  }
+#define XR_ROW(u) xr_row[u]
+#define XR_KD(u) xr_kd[u]
+#define XR_KH(u) xr_kh[u]
+#define XR_OUT(u) xr_out[u]
+#define XR_CI(u) xr_ci[u]
+#define XR_VALID(u) xr_valid[u]
+
+  // workgroups b and b+8 run on the same XCD (one L2): give each XCD a contiguous range of tiles
+  const int lblock = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
+  const int tile0 = lblock * iters;
+  struct Tile {
+    int n, od, p, g4;  // wave-uniform
+  };
+  auto tile_at = [&](int it) {
+    Tile t;
+    int T = tile0 + it;
+    T = __builtin_amdgcn_readfirstlane(T < tiles_total ? T : tiles_total - 1);
+    t.g4 = T % gpc;
+    int q = T / gpc;
+    t.p = q & 1;
+    q >>= 1;
+    t.od = q % OD;
+    t.n = q / OD;
+    return t;
+  };
+  u32x4 Y[8];                       // fp32: 4 values; bf16: .xy hold 4 values
+  u32x2 DZ[8][4];                   // slot t = td * 2 + th; fp32: 2 values; bf16: .x holds 2 values
+  u32x4 X[NXL];
+  // Two input channels: 9 row-pair loads per wave would keep 36 more registers alive across the MFMA phase (spills at
+  // 2 waves per SIMD), so there the rows are requested inside the produce phase, once the dz registers are dead.
+  constexpr bool XLATE = CIN > 1;
+  auto issue_x = [&](const Tile& t) {
+#pragma unroll
+    for (int u = 0; u < NXL; ++u) {
+      const int id = 2 * t.od - 1 + XR_KD(u), ih = 2 * (t.p + 2 * (4 * t.g4 + XR_OUT(u))) - 1 + XR_KH(u);
+      const bool ok = id >= 0 && id < D && ih >= 0 && ih < H;
+      const unsigned off = ((((unsigned)(t.n * CIN + XR_CI(u)) * D + (ok ? id : 0)) * H + (ok ? ih : 0)) * W + 4u * (lane & 31)) * 4u;
+      X[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+    }
+  };
+  auto issue = [&](const Tile& t) {
+    const int qr = 4 * t.g4 + r;
+    const int yv = (int)(((unsigned)(t.p + 2 * qr) * OW + 4u * m) * ES);
+    unsigned ys = (((unsigned)(t.n * 32 + 8 * wv)) * OS + (unsigned)t.od * OH * OW) * ES;
+#pragma unroll
+    for (int k = 0; k < 8; ++k, ys += OS * ES) {
+      if constexpr (BF16ACT) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ry, yv, (int)ys, 0);
+        Y[k] = (u32x4){v.x, v.y, 0u, 0u};
+      } else {
+        Y[k] = __builtin_amdgcn_raw_buffer_load_b128(ry, yv, (int)ys, 0);
+      }
+    }
+    const bool pd = t.od & 1;
+    int idD[2], idH[2];
+    idD[0] = pd ? (t.od + 1) >> 1 : t.od >> 1;
+    if (idD[0] >= OD1) idD[0] = t.od >> 1;  // dead slot: re-read a live plane
+    idD[1] = t.od >> 1;
+    idH[0] = t.p ? qr + 1 : qr;
+    if (idH[0] >= OH1) idH[0] = qr;         // (per lane) masked in consume
+    idH[1] = qr;
+#pragma unroll
+    for (int td = 0; td < 2; ++td) {
+#pragma unroll
+      for (int th = 0; th < 2; ++th) {
+        const int dv = (int)(((unsigned)idH[th] * OW1 + 2u * m) * ES);
+        unsigned ds = (((unsigned)(t.n * 32 + 8 * wv)) * OS1 + (unsigned)idD[td] * OH1 * OW1) * ES;
+#pragma unroll
+        for (int k = 0; k < 8; ++k, ds += OS1 * ES) {
+          if constexpr (BF16ACT) {
+            DZ[k][td * 2 + th] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rdz, dv, (int)ds, 0), 0u};
+          } else {
+            DZ[k][td * 2 + th] = __builtin_amdgcn_raw_buffer_load_b64(rdz, dv, (int)ds, 0);
+          }
+        }
+      }
+    }
+    if constexpr (!XLATE) issue_x(t);
+  };
+  auto val = [](unsigned bits, int e) {  // element e of a pair of packed bf16
+    return __uint_as_float(e ? (bits & 0xffff0000u) : (bits << 16));
+  };
+  auto consume = [&](const Tile& t) {
+    const int qr = 4 * t.g4 + r;
+    const bool pd = t.od & 1;
+    const bool okH0 = (t.p ? qr + 1 : qr) < OH1;          // per lane
+    const bool vD[2] = {(pd ? (t.od + 1) >> 1 : t.od >> 1) < OD1, pd};
+    const bool vH[2] = {true, (bool)t.p};
+    const int kD[2] = {pd ? 0 : 1, 2}, kH[2] = {t.p ? 0 : 1, 2};
+    // slot-outer, channel-inner: the three taps of a slot for the wave's 8 channels are three s_load_dwordx8 (tap-major
+    // weights), i.e. one scalar round trip per live slot and one for the BatchNorm vectors - not one per (slot, channel)
+    float g[8][4];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) g[k][0] = g[k][1] = g[k][2] = g[k][3] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int td = s >> 1, th = s & 1;
+      if (vD[td] && vH[th]) {  // wave-uniform
+        const float* wk = w1p + (kD[td] * 9 + kH[th] * 3) * 32 + 8 * wv;  // tap-major (27, 32)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          float a, b;
+          if constexpr (BF16ACT) { a = val(DZ[k][s].x, 0); b = val(DZ[k][s].x, 1); }
+          else { a = __uint_as_float(DZ[k][s].x); b = __uint_as_float(DZ[k][s].y); }
+          if (th == 0) { a = okH0 ? a : 0.f; b = okH0 ? b : 0.f; }
+          const float nb = msl::dpp_mov<0x101>(a);  // row_shl:1: dz[2m+2] = the next lane's first value, 0 past the row
+          const float w0 = wk[k], w1 = wk[32 + k], w2 = wk[64 + k];
+          g[k][0] = fmaf(w1, a, g[k][0]);
+          g[k][1] = fmaf(w2, a, g[k][1]);
+          g[k][1] = fmaf(w0, b, g[k][1]);
+          g[k][2] = fmaf(w1, b, g[k][2]);
+          g[k][3] = fmaf(w2, b, g[k][3]);
+          g[k][3] = fmaf(w0, nb, g[k][3]);
+        }
+      }
+    }
+    if constexpr (XLATE) {
+      issue_x(t);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      const int c = 8 * wv + k;
+      const float sc = bnv[c], sf = bnv[32 + c], cC = bnv[192 + c], cE = bnv[224 + c];
+      float y0, y1, y2, y3;
+      if constexpr (BF16ACT) { y0 = val(Y[k].x, 0); y1 = val(Y[k].x, 1); y2 = val(Y[k].y, 0); y3 = val(Y[k].y, 1); }
+      else { y0 = __uint_as_float(Y[k].x); y1 = __uint_as_float(Y[k].y); y2 = __uint_as_float(Y[k].z); y3 = __uint_as_float(Y[k].w); }
+      float4 v;
+      v.x = fmaf(sc, fmaf(y0, sc, sf) > 0.f ? g[k][0] : 0.f, fmaf(cC, y0, cE));  // scale*gm + (cC*y + cE)
+      v.y = fmaf(sc, fmaf(y1, sc, sf) > 0.f ? g[k][1] : 0.f, fmaf(cC, y1, cE));
+      v.z = fmaf(sc, fmaf(y2, sc, sf) > 0.f ? g[k][2] : 0.f, fmaf(cC, y2, cE));
+      v.w = fmaf(sc, fmaf(y3, sc, sf) > 0.f ? g[k][3] : 0.f, fmaf(cC, y3, cE));
+      *reinterpret_cast<float4*>(At + c * SBT_LDA + 4 * lane) = v;
+    }
+#pragma unroll
+    for (int u = 0; u < NXL; ++u) {
+      const int id = 2 * t.od - 1 + XR_KD(u), ih = 2 * (t.p + 2 * (4 * t.g4 + XR_OUT(u))) - 1 + XR_KH(u);
+      const bool ok = id >= 0 && id < D && ih >= 0 && ih < H;
+      if (XR_VALID(u)) {
+        float* dst = rows + XR_ROW(u) * SBT_RP + 1 + 4 * (lane & 31);
+        dst[0] = ok ? __uint_as_float(X[u].x) : 0.f;
+        dst[1] = ok ? __uint_as_float(X[u].y) : 0.f;
+        dst[2] = ok ? __uint_as_float(X[u].z) : 0.f;
+        dst[3] = ok ? __uint_as_float(X[u].w) : 0.f;
+      }
+    }
+  };
+
+  Tile cur = tile_at(0);
+  issue(cur);
+  for (int it = 0; it < iters; ++it) {
+    if (tile0 + it >= tiles_total) break;  // uniform over the workgroup
+    consume(cur);
+    __syncthreads();
+    if (it + 1 < iters && tile0 + it + 1 < tiles_total) {  // uniform
+      cur = tile_at(it + 1);
+      issue(cur);  // in flight during the MFMAs
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const float* arow = At + (lane & 31) * SBT_LDA + 64 * wv + 4 * h;
+    const float* brow = rows + wv * (CIN * 9 * SBT_RP) + 8 * h;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * q);
+      const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const float b = brow[tapoff[nt] + 2 * (8 * q + j)];
+          acc[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[j], b, acc[nt], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // fixed-order reduction over the 4 waves through LDS, then one slab per block: slab[32][32*NT]
+  __syncthreads();
+  float* red = lds;
+  for (int w2 = 3; w2 >= 1; --w2) {
+    if (wv == w2) {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) {
+          const int row = (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+          float* p = red + row * (32 * NT) + nt * 32 + (lane & 31);
+          if (w2 == 3) *p = acc[nt][rg];
+          else *p += acc[nt][rg];
+        }
+    }
+    __syncthreads();
+  }
+  if (wv == 0) {
+    float* out = slabs + (size_t)blockIdx.x * 32 * 32 * NT;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int rg = 0; rg < 16; ++rg) {
+        const int row = (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+        const int idx = row * (32 * NT) + nt * 32 + (lane & 31);
+        out[idx] = acc[nt][rg] + red[idx];
+      }
+  }
+}
+
+#undef XR_ROW
+#undef XR_KD
+#undef XR_KH
+#undef XR_OUT
+#undef XR_CI
+#undef XR_VALID
+
 __global__ __launch_bounds__(256) void stem_bwd_weight_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                                      int K, int NT, int nslabs) {
   __shared__ float lds[8 * 33];
@@ -1009,6 +1303,34 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
   const int NT = (Cin * 27 + 31) / 32;
   const size_t lds = (size_t)4 * (32 * SB_DY_LD + Cin * 9 * SB_ROW_LD) * sizeof(float);
   const StemFusedSrc fs{(OD - 1) / 2 + 1, (OH - 1) / 2 + 1, (OW - 1) / 2 + 1};
+  static const int tile_on = getenv("MSL_STEM_BWW_TILE") ? atoi(getenv("MSL_STEM_BWW_TILE")) : 1;
+  if (tile_on && w1 && sd == 2 && sh == 2 && sw == 2 && W == 128 && H % 16 == 0 && Cin <= 2 &&
+      (long long)N * Cin * D * H * W * 4 < (1ll << 32)) {
+    // tile-staged form (stem_bww_tile_kernel): a workgroup per 4 output rows of one parity; same slab count as below
+    const int tiles_total = N * OD * (OH / 4);
+    const int nb = std::min(stem_bw_blocks(), tiles_total);
+    const int it = msl::cdiv(tiles_total, nb);
+    const size_t tl = (size_t)(32 * SBT_LDA + 36 * Cin * SBT_RP) * sizeof(float);
+#define MSL_STEM_BWT(CI, B_)                                                                                         \
+  do {                                                                                                               \
+    if (tl > 64 * 1024) {                                                                                            \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bww_tile_kernel<CI, B_>),               \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);                      \
+      if (e_ != hipSuccess) return (int)e_;                                                                          \
+    }                                                                                                                \
+    hipLaunchKernelGGL((stem_bww_tile_kernel<CI, B_>), dim3(nb), dim3(256), tl, st, (const void*)dy, (const void*)yraw, \
+                       x, workspace, N, D, H, OD, OH, tiles_total, it, bnv, w1);                                     \
+  } while (0)
+    if (Cin == 1) { if (bf16act) MSL_STEM_BWT(1, true); else MSL_STEM_BWT(1, false); }
+    else { if (bf16act) MSL_STEM_BWT(2, true); else MSL_STEM_BWT(2, false); }
+#undef MSL_STEM_BWT
+    MSL_LAUNCH_CHECK();
+    if (!dw) return MSL_OK;
+    hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw,
+                       Cin * 27, NT, nb);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
 #define MSL_STEM_BW1(CI, AP)                                                                                         \
   do {                                                                                                               \
     if (lds > 64 * 1024) {                                                                                           \

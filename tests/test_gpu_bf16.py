@@ -284,7 +284,8 @@ def test_dw_s2_bwd_data_with_bn_reduce_bf16(N, C, dims):
     close(dbet, beta.grad, 1e-3, tol, "dbeta from the fused reduce")
 
 
-@pytest.mark.parametrize("cin,dims", [(1, (12, 16, 24)), (2, (16, 16, 16)), (1, (32, 32, 32))])
+@pytest.mark.parametrize("cin,dims", [(1, (12, 16, 24)), (2, (16, 16, 16)), (1, (32, 32, 32)),
+                                      (1, (5, 48, 128)), (2, (6, 32, 128)), (1, (40, 64, 128))])  # the tile-staged kernel
 def test_fused_stem_backward_bf16(cin, dims):
     """The fused stem backward on bf16 storage: one pass over (dL/dz_1, y_0) for the stem's BatchNorm sums and block 1's
     depthwise weight gradient, then the stem weight gradient rebuilding dL/d(stem activation) from dL/dz_1 on the fly ==

@@ -246,7 +246,11 @@ def test_fused_bn_backward_of_the_stem_tail():
     close(dw, w0.grad, 2e-4, 1e-4, "stem dW with fused BN apply")
 
 
-@pytest.mark.parametrize("cin,dims", [(1, (12, 16, 24)), (2, (16, 16, 16)), (1, (10, 14, 72))])
+@pytest.mark.parametrize("cin,dims", [(1, (12, 16, 24)), (2, (16, 16, 16)), (1, (10, 14, 72)),
+                                      # W == 128, H % 16 == 0: the tile-staged kernel (stem_bww_tile_kernel) - one / odd /
+                                      # even plane counts, both parities at every border, two channels, and 768 tiles on
+                                      # 512 workgroups (two tiles per workgroup, a quarter of the workgroups idle)
+                                      (1, (2, 16, 128)), (1, (5, 48, 128)), (2, (6, 32, 128)), (1, (96, 64, 128))])
 def test_stem_backward_without_materialising_the_activation_gradient(cin, dims):
     """One pass over (dL/dz_1, y_0) for the BatchNorm sums and the depthwise weight gradient, then the stem weight
     gradient rebuilding dL/d(stem activation) from dL/dz_1 on the fly == CPU autograd through
@@ -294,7 +298,8 @@ def _fused_stem_case(cin, dims):
     ws = torch.empty(L.msl_stem_conv_bwd_weight_workspace_bytes(cin) // 4, device=DEV)
     _lib.call("msl_stem_conv_bwd_weight_fused", ptr(dzd), ptr(w1t), ptr(y0d), ptr(vec), ptr(K(x)), ptr(dw), ptr(ws), N, cin,
               *dims, 2, 2, 2, st())
-    close(dw, w0.grad, 2e-4, 1e-4, "stem dW with the gradient rebuilt on the fly")
+    # fp32 accumulation over N * OD * OH * OW positions: the absolute bar scales with the tensor's magnitude
+    close(dw, w0.grad, 2e-4, max(1e-4, 2e-6 * float(w0.grad.abs().max())), "stem dW with the gradient rebuilt on the fly")
 
 
 # ------------------------------------------------------------------------------------------------- pointwise
