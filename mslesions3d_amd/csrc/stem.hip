@@ -853,16 +853,19 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_kernel(const float* __res
 constexpr int SBT_LDA = 260;  // g-tile pitch in floats: rows 16-byte aligned and (pitch / 4) odd -> conflict-free ds_read_b128
 constexpr int SBT_RP = 131;   // input-row pitch (1 + 128 used); 131 % 32 == 3
 
-template <int CIN, bool BF16ACT>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void stem_bww_tile_kernel(const void* __restrict__ dzp, const void* __restrict__ yp,
+// NW = waves per workgroup (4 or 8): wave w produces channels [CPW*w, CPW*(w+1)), CPW = 32 / NW, and multiplies positions
+// [PPW*w, PPW*(w+1)), PPW = 256 / NW, of the tile.
+template <int CIN, bool BF16ACT, int NW>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(NW == 8 ? 4 : 2))) void stem_bww_tile_kernel(const void* __restrict__ dzp, const void* __restrict__ yp,
                                                             const float* __restrict__ x, float* __restrict__ slabs, int N,
                                                             int D, int H, int OD, int OH, int tiles_total, int iters,
                                                             const float* __restrict__ bnv, const float* __restrict__ w1p) {
+  constexpr int CPW = 32 / NW, PPW = 256 / NW;
   constexpr unsigned ES = BF16ACT ? 2u : 4u;
   constexpr int NT = (CIN * 27 + 31) / 32;
   constexpr int W = 128, OW = 64, OW1 = 32;
   constexpr int NROWS = 4 * CIN * 9;             // input rows of a tile
-  constexpr int NXL = (NROWS / 2 + 3) / 4;       // row-pair loads per wave and tile
+  constexpr int NXL = (NROWS / 2 + NW - 1) / NW;       // row-pair loads per wave and tile
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   extern __shared__ __align__(16) float lds[];
@@ -888,7 +891,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   f32x16 acc[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x16){0};
-  for (int R = threadIdx.x; R < NROWS; R += 256) rows[R * SBT_RP] = 0.f;  // column iw = -1 of every row
+  for (int R = threadIdx.x; R < NROWS; R += NW * 64) rows[R * SBT_RP] = 0.f;  // column iw = -1 of every row
 
   const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(
       (void*)msl::uniform_base(yp), 0, (int)((unsigned)N * 32u * OS * ES), 0x00020000);
@@ -898,26 +901,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       (void*)msl::uniform_base(x), 0, (int)((unsigned)N * CIN * D * H * W * 4u), 0x00020000);
 
   // the input rows this lane fetches: pair u of the wave = rows 2*(wv + 4u) + h, constant over the tiles
-  int xr_out[NXL], xr_ci[NXL], xr_kd[NXL], xr_kh[NXL], xr_row[NXL];
-  bool xr_valid[NXL];
+  // lane-constant parts: byte offset of (ci, kd, 4 * out + kh, column) inside x, LDS element of the row, and which border
+  // can put the row outside the volume (then the lane stores zeros)
+  int xr_off[NXL], xr_dst[NXL];
+  bool xr_valid[NXL], xr_kd0[NXL], xr_kd2[NXL], xr_top[NXL];
 #pragma unroll
   for (int u = 0; u < NXL; ++u) {
-    const int R = 2 * (wv + 4 * u) + h;
+    const int R = 2 * (wv + NW * u) + h;
     xr_valid[u] = R < NROWS;
     const int Rc = xr_valid[u] ? R : 0;
-    xr_row[u] = Rc;
-    xr_out[u] = Rc / (CIN * 9);
-    const int rem = Rc % (CIN * 9);
-    xr_ci[u] = rem / 9;
-    xr_kd[u] = (rem % 9) / 3;
-    xr_kh[u] = rem % 3;
+    const int out = Rc / (CIN * 9), rem = Rc % (CIN * 9), ci = rem / 9, kd = (rem % 9) / 3, kh = rem % 3;
+    xr_off[u] = (((ci * D + kd) * H + 4 * out + kh) * W + 4 * (lane & 31)) * 4;
+    xr_dst[u] = Rc * SBT_RP + 1 + 4 * (lane & 31);
+    xr_kd0[u] = kd == 0;
+    xr_kd2[u] = kd == 2;
+    xr_top[u] = out == 0 && kh == 0;
   }
-#define XR_ROW(u) xr_row[u]
-#define XR_KD(u) xr_kd[u]
-#define XR_KH(u) xr_kh[u]
-#define XR_OUT(u) xr_out[u]
-#define XR_CI(u) xr_ci[u]
-#define XR_VALID(u) xr_valid[u]
+  // input row (id, ih) = (2 od - 1 + kd, 4 (4 g4 + out) + 2 p - 1 + kh): outside the volume only for kd == 0 at od == 0,
+  // kd == 2 at the last plane of an odd D, and kh == 0 in the first row of the first tile of parity 0
+#define XR_OK(u, t) (!((xr_kd0[u] & ((t).od == 0)) | (xr_kd2[u] & (2 * (t).od + 1 >= D)) | (xr_top[u] & (((t).g4 | (t).p) == 0))))
 
   // workgroups b and b+8 run on the same XCD (one L2): give each XCD a contiguous range of tiles
   const int lblock = (gridDim.x & 7) == 0 ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
@@ -925,10 +927,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   struct Tile {
     int n, od, p, g4;  // wave-uniform
   };
-  auto tile_at = [&](int it) {
+  auto tile_first = [&]() {  // the workgroup's tiles are consecutive: decode once, then count
     Tile t;
-    int T = tile0 + it;
-    T = __builtin_amdgcn_readfirstlane(T < tiles_total ? T : tiles_total - 1);
+    const int T = __builtin_amdgcn_readfirstlane(tile0 < tiles_total ? tile0 : tiles_total - 1);
     t.g4 = T % gpc;
     int q = T / gpc;
     t.p = q & 1;
@@ -937,8 +938,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     t.n = q / OD;
     return t;
   };
-  u32x4 Y[8];                       // fp32: 4 values; bf16: .xy hold 4 values
-  u32x2 DZ[8][4];                   // slot t = td * 2 + th; fp32: 2 values; bf16: .x holds 2 values
+  auto tile_next = [&](Tile t) {
+    if (++t.g4 == gpc) {
+      t.g4 = 0;
+      if ((t.p ^= 1) == 0 && ++t.od == OD) {
+        t.od = 0;
+        ++t.n;
+      }
+    }
+    return t;
+  };
+  u32x4 Y[CPW];                       // fp32: 4 values; bf16: .xy hold 4 values
+  u32x2 DZ[CPW][4];                   // slot t = td * 2 + th; fp32: 2 values; bf16: .x holds 2 values
   u32x4 X[NXL];
   // Two input channels: 9 row-pair loads per wave would keep 36 more registers alive across the MFMA phase (spills at
   // 2 waves per SIMD), so there the rows are requested inside the produce phase, once the dz registers are dead.
@@ -946,18 +957,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   auto issue_x = [&](const Tile& t) {
 #pragma unroll
     for (int u = 0; u < NXL; ++u) {
-      const int id = 2 * t.od - 1 + XR_KD(u), ih = 2 * (t.p + 2 * (4 * t.g4 + XR_OUT(u))) - 1 + XR_KH(u);
-      const bool ok = id >= 0 && id < D && ih >= 0 && ih < H;
-      const unsigned off = ((((unsigned)(t.n * CIN + XR_CI(u)) * D + (ok ? id : 0)) * H + (ok ? ih : 0)) * W + 4u * (lane & 31)) * 4u;
-      X[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, (int)off, 0, 0);
+      const int xt = (((t.n * CIN * D + 2 * t.od - 1) * H + 16 * t.g4 + 2 * t.p - 1) * W) * 4;  // scalar
+      X[u] = __builtin_amdgcn_raw_buffer_load_b128(rx, XR_OK(u, t) ? xr_off[u] + xt : 0, 0, 0);
     }
   };
   auto issue = [&](const Tile& t) {
     const int qr = 4 * t.g4 + r;
     const int yv = (int)(((unsigned)(t.p + 2 * qr) * OW + 4u * m) * ES);
-    unsigned ys = (((unsigned)(t.n * 32 + 8 * wv)) * OS + (unsigned)t.od * OH * OW) * ES;
+    unsigned ys = (((unsigned)(t.n * 32 + CPW * wv)) * OS + (unsigned)t.od * OH * OW) * ES;
 #pragma unroll
-    for (int k = 0; k < 8; ++k, ys += OS * ES) {
+    for (int k = 0; k < CPW; ++k, ys += OS * ES) {
       if constexpr (BF16ACT) {
         const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(ry, yv, (int)ys, 0);
         Y[k] = (u32x4){v.x, v.y, 0u, 0u};
@@ -978,9 +987,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
 #pragma unroll
       for (int th = 0; th < 2; ++th) {
         const int dv = (int)(((unsigned)idH[th] * OW1 + 2u * m) * ES);
-        unsigned ds = (((unsigned)(t.n * 32 + 8 * wv)) * OS1 + (unsigned)idD[td] * OH1 * OW1) * ES;
+        unsigned ds = (((unsigned)(t.n * 32 + CPW * wv)) * OS1 + (unsigned)idD[td] * OH1 * OW1) * ES;
 #pragma unroll
-        for (int k = 0; k < 8; ++k, ds += OS1 * ES) {
+        for (int k = 0; k < CPW; ++k, ds += OS1 * ES) {
           if constexpr (BF16ACT) {
             DZ[k][td * 2 + th] = (u32x2){__builtin_amdgcn_raw_buffer_load_b32(rdz, dv, (int)ds, 0), 0u};
           } else {
@@ -998,33 +1007,35 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     const int qr = 4 * t.g4 + r;
     const bool pd = t.od & 1;
     const bool okH0 = (t.p ? qr + 1 : qr) < OH1;          // per lane
+    const bool edgeH = t.p && t.g4 == gpc - 1;            // wave-uniform: only the last tile of parity 1 has such lanes
     const bool vD[2] = {(pd ? (t.od + 1) >> 1 : t.od >> 1) < OD1, pd};
     const bool vH[2] = {true, (bool)t.p};
     const int kD[2] = {pd ? 0 : 1, 2}, kH[2] = {t.p ? 0 : 1, 2};
     // slot-outer, channel-inner: the three taps of a slot for the wave's 8 channels are three s_load_dwordx8 (tap-major
     // weights), i.e. one scalar round trip per live slot and one for the BatchNorm vectors - not one per (slot, channel)
-    float g[8][4];
+    // packed pairs: ge = (g0, g2) and go = (g1, g3) of the lane's four positions, so that a slot is three v_pk_fma_f32 with
+    // a broadcast scalar tap:  ge += w1 * (a, b);  go += w2 * (a, b);  go += w0 * (b, nb)
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    v2f ge[CPW], go[CPW];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) g[k][0] = g[k][1] = g[k][2] = g[k][3] = 0.f;
+    for (int k = 0; k < CPW; ++k) ge[k] = go[k] = (v2f){0.f, 0.f};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
       const int td = s >> 1, th = s & 1;
       if (vD[td] && vH[th]) {  // wave-uniform
-        const float* wk = w1p + (kD[td] * 9 + kH[th] * 3) * 32 + 8 * wv;  // tap-major (27, 32)
+        const float* wk = w1p + (kD[td] * 9 + kH[th] * 3) * 32 + CPW * wv;  // tap-major (27, 32)
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
+        for (int k = 0; k < CPW; ++k) {
           float a, b;
           if constexpr (BF16ACT) { a = val(DZ[k][s].x, 0); b = val(DZ[k][s].x, 1); }
           else { a = __uint_as_float(DZ[k][s].x); b = __uint_as_float(DZ[k][s].y); }
-          if (th == 0) { a = okH0 ? a : 0.f; b = okH0 ? b : 0.f; }
+          if (th == 0 && edgeH) { a = okH0 ? a : 0.f; b = okH0 ? b : 0.f; }
           const float nb = msl::dpp_mov<0x101>(a);  // row_shl:1: dz[2m+2] = the next lane's first value, 0 past the row
           const float w0 = wk[k], w1 = wk[32 + k], w2 = wk[64 + k];
-          g[k][0] = fmaf(w1, a, g[k][0]);
-          g[k][1] = fmaf(w2, a, g[k][1]);
-          g[k][1] = fmaf(w0, b, g[k][1]);
-          g[k][2] = fmaf(w1, b, g[k][2]);
-          g[k][3] = fmaf(w2, b, g[k][3]);
-          g[k][3] = fmaf(w0, nb, g[k][3]);
+          const v2f ab = {a, b}, bn = {b, nb};
+          ge[k] = __builtin_elementwise_fma((v2f){w1, w1}, ab, ge[k]);
+          go[k] = __builtin_elementwise_fma((v2f){w2, w2}, ab, go[k]);
+          go[k] = __builtin_elementwise_fma((v2f){w0, w0}, bn, go[k]);
         }
       }
     }
@@ -1033,25 +1044,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
       __builtin_amdgcn_sched_barrier(0);
     }
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-      const int c = 8 * wv + k;
+    for (int k = 0; k < CPW; ++k) {
+      const int c = CPW * wv + k;
       const float sc = bnv[c], sf = bnv[32 + c], cC = bnv[192 + c], cE = bnv[224 + c];
       float y0, y1, y2, y3;
       if constexpr (BF16ACT) { y0 = val(Y[k].x, 0); y1 = val(Y[k].x, 1); y2 = val(Y[k].y, 0); y3 = val(Y[k].y, 1); }
       else { y0 = __uint_as_float(Y[k].x); y1 = __uint_as_float(Y[k].y); y2 = __uint_as_float(Y[k].z); y3 = __uint_as_float(Y[k].w); }
-      float4 v;
-      v.x = fmaf(sc, fmaf(y0, sc, sf) > 0.f ? g[k][0] : 0.f, fmaf(cC, y0, cE));  // scale*gm + (cC*y + cE)
-      v.y = fmaf(sc, fmaf(y1, sc, sf) > 0.f ? g[k][1] : 0.f, fmaf(cC, y1, cE));
-      v.z = fmaf(sc, fmaf(y2, sc, sf) > 0.f ? g[k][2] : 0.f, fmaf(cC, y2, cE));
-      v.w = fmaf(sc, fmaf(y3, sc, sf) > 0.f ? g[k][3] : 0.f, fmaf(cC, y3, cE));
-      *reinterpret_cast<float4*>(At + c * SBT_LDA + 4 * lane) = v;
+      // scale*gm + (cC*y + cE), two values per v_pk_fma_f32
+      const v2f sc2 = {sc, sc}, sf2 = {sf, sf}, cC2 = {cC, cC}, cE2 = {cE, cE};
+      const v2f ya = {y0, y1}, yb = {y2, y3};
+      const v2f ta = __builtin_elementwise_fma(ya, sc2, sf2), tb = __builtin_elementwise_fma(yb, sc2, sf2);
+      const v2f ga = {ta.x > 0.f ? ge[k].x : 0.f, ta.y > 0.f ? go[k].x : 0.f};
+      const v2f gb = {tb.x > 0.f ? ge[k].y : 0.f, tb.y > 0.f ? go[k].y : 0.f};
+      const v2f va = __builtin_elementwise_fma(sc2, ga, __builtin_elementwise_fma(cC2, ya, cE2));
+      const v2f vb = __builtin_elementwise_fma(sc2, gb, __builtin_elementwise_fma(cC2, yb, cE2));
+      *reinterpret_cast<float4*>(At + c * SBT_LDA + 4 * lane) = make_float4(va.x, va.y, vb.x, vb.y);
     }
 #pragma unroll
     for (int u = 0; u < NXL; ++u) {
-      const int id = 2 * t.od - 1 + XR_KD(u), ih = 2 * (t.p + 2 * (4 * t.g4 + XR_OUT(u))) - 1 + XR_KH(u);
-      const bool ok = id >= 0 && id < D && ih >= 0 && ih < H;
-      if (XR_VALID(u)) {
-        float* dst = rows + XR_ROW(u) * SBT_RP + 1 + 4 * (lane & 31);
+      const bool ok = XR_OK(u, t);
+      if (xr_valid[u]) {
+        float* dst = rows + xr_dst[u];
         dst[0] = ok ? __uint_as_float(X[u].x) : 0.f;
         dst[1] = ok ? __uint_as_float(X[u].y) : 0.f;
         dst[2] = ok ? __uint_as_float(X[u].z) : 0.f;
@@ -1060,21 +1073,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
     }
   };
 
-  Tile cur = tile_at(0);
+  Tile cur = tile_first();
   issue(cur);
   for (int it = 0; it < iters; ++it) {
     if (tile0 + it >= tiles_total) break;  // uniform over the workgroup
     consume(cur);
     __syncthreads();
     if (it + 1 < iters && tile0 + it + 1 < tiles_total) {  // uniform
-      cur = tile_at(it + 1);
+      cur = tile_next(cur);
       issue(cur);  // in flight during the MFMAs
     }
     __builtin_amdgcn_sched_barrier(0);
-    const float* arow = At + (lane & 31) * SBT_LDA + 64 * wv + 4 * h;
-    const float* brow = rows + wv * (CIN * 9 * SBT_RP) + 8 * h;
+    const float* arow = At + (lane & 31) * SBT_LDA + PPW * wv + 4 * h;
+    const float* brow = rows + ((PPW * wv) >> 6) * (CIN * 9 * SBT_RP) + 2 * ((PPW * wv) & 63) + 8 * h;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < PPW / 8; ++q) {
       const float4 a4 = *reinterpret_cast<const float4*>(arow + 8 * q);
       const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
@@ -1091,7 +1104,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   // fixed-order reduction over the 4 waves through LDS, then one slab per block: slab[32][32*NT]
   __syncthreads();
   float* red = lds;
-  for (int w2 = 3; w2 >= 1; --w2) {
+  for (int w2 = NW - 1; w2 >= 1; --w2) {
     if (wv == w2) {
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
@@ -1099,7 +1112,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
         for (int rg = 0; rg < 16; ++rg) {
           const int row = (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
           float* p = red + row * (32 * NT) + nt * 32 + (lane & 31);
-          if (w2 == 3) *p = acc[nt][rg];
+          if (w2 == NW - 1) *p = acc[nt][rg];
           else *p += acc[nt][rg];
         }
     }
@@ -1118,12 +1131,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void s
   }
 }
 
-#undef XR_ROW
-#undef XR_KD
-#undef XR_KH
-#undef XR_OUT
-#undef XR_CI
-#undef XR_VALID
+#undef XR_OK
 
 __global__ __launch_bounds__(256) void stem_bwd_weight_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                                      int K, int NT, int nslabs) {
@@ -1311,19 +1319,26 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
     const int nb = std::min(stem_bw_blocks(), tiles_total);
     const int it = msl::cdiv(tiles_total, nb);
     const size_t tl = (size_t)(32 * SBT_LDA + 36 * Cin * SBT_RP) * sizeof(float);
-#define MSL_STEM_BWT(CI, B_)                                                                                         \
+    static const int tile_nw = getenv("MSL_STEM_BWW_NW") ? atoi(getenv("MSL_STEM_BWW_NW")) : 4;
+#define MSL_STEM_BWT2(CI, B_, NW_)                                                                                   \
   do {                                                                                                               \
     if (tl > 64 * 1024) {                                                                                            \
-      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bww_tile_kernel<CI, B_>),               \
+      hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_bww_tile_kernel<CI, B_, NW_>),          \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);                      \
       if (e_ != hipSuccess) return (int)e_;                                                                          \
     }                                                                                                                \
-    hipLaunchKernelGGL((stem_bww_tile_kernel<CI, B_>), dim3(nb), dim3(256), tl, st, (const void*)dy, (const void*)yraw, \
-                       x, workspace, N, D, H, OD, OH, tiles_total, it, bnv, w1);                                     \
+    hipLaunchKernelGGL((stem_bww_tile_kernel<CI, B_, NW_>), dim3(nb), dim3(NW_ * 64), tl, st, (const void*)dy,       \
+                       (const void*)yraw, x, workspace, N, D, H, OD, OH, tiles_total, it, bnv, w1);                  \
+  } while (0)
+#define MSL_STEM_BWT(CI, B_)                          \
+  do {                                                \
+    if (tile_nw == 8) MSL_STEM_BWT2(CI, B_, 8);       \
+    else MSL_STEM_BWT2(CI, B_, 4);                    \
   } while (0)
     if (Cin == 1) { if (bf16act) MSL_STEM_BWT(1, true); else MSL_STEM_BWT(1, false); }
     else { if (bf16act) MSL_STEM_BWT(2, true); else MSL_STEM_BWT(2, false); }
 #undef MSL_STEM_BWT
+#undef MSL_STEM_BWT2
     MSL_LAUNCH_CHECK();
     if (!dw) return MSL_OK;
     hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw,
