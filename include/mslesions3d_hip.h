@@ -149,6 +149,13 @@ int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale
 int msl_pwconv_bwd_weight_nslabs(int N, int Cin, int Cout, int S);
 int msl_pwconv_bwd_weight_slabs(const float* dy, const float* z, const float* in_scale, const float* in_shift,
                                 float* out, int N, int Cin, int Cout, int S, void* stream);
+/* the same for n <= 4 layers in ONE launch (the tail blocks, whose launches are pure latency): the eight arrays have n
+ * entries and live on the host; every layer must be batchable (msl_pwconv_bwd_weight_batchable == 1) and carries its
+ * input affine.  out[k] as `out` above for layer k.  Same arithmetic and slabs as n single calls: mobilenet.py:40 */
+int msl_pwconv_bwd_weight_batchable(int N, int Cin, int Cout, int S);
+int msl_pwconv_bwd_weight_slabs_batch(const float* const* dy, const float* const* z, const float* const* in_scale,
+                                      const float* const* in_shift, float* const* out, const int* Cin, const int* Cout,
+                                      const int* S, int n, int N, void* stream);
 
 /* ---- detection heads: loc (C->12) + cls (C->2*ncls) k3 p1 convs, permute/view/cat fused : ssd3d.py:113-169 - */
 size_t msl_head_packed_weight_elems(int C, int ncls);
@@ -163,6 +170,9 @@ int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, c
                       int ncls, void* stream);
 int msl_head_grad_pack(const float* dlocs, const float* dscores, float* dO_pad, int N, int D, int H, int W,
                        int Ptot, int prior_off, int ncls, void* stream);
+/* the same for all (n <= 4) scales in one launch; dO_pad / D / H / W / prior_off are host arrays of n entries */
+int msl_head_grad_pack_batch(const float* dlocs, const float* dscores, float* const* dO_pad, const int* D, const int* H,
+                             const int* W, const int* prior_off, int n, int N, int Ptot, int ncls, void* stream);
 int msl_head_conv_bwd_data(const float* dO_pad, const float* Wb, float* g_a, int N, int C, int D, int H, int W,
                            int ncls, void* stream);
 size_t msl_head_bwd_weight_workspace_bytes(int N, int C, int D, int H, int W, int ncls);

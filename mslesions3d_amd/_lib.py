@@ -58,6 +58,8 @@ _SIGNATURES = {
     "msl_pwconv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_pwconv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I]),
     "msl_pwconv_bwd_weight_slabs": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "msl_pwconv_bwd_weight_batchable": (_I, [_I, _I, _I, _I]),
+    "msl_pwconv_bwd_weight_slabs_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "msl_stem_conv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "msl_head_conv_bwd_weight_nslabs": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_grad_reduce_entry_bytes": (_Z, []),
@@ -69,6 +71,7 @@ _SIGNATURES = {
     "msl_head_fwd_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "msl_head_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_head_grad_pack": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_head_grad_pack_batch": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_head_conv_bwd_data": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_head_bwd_weight_workspace_bytes": (_Z, [_I, _I, _I, _I, _I, _I]),
     "msl_head_conv_bwd_weight": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

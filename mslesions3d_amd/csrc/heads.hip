@@ -238,6 +238,31 @@ __global__ __launch_bounds__(256) void head_grad_pack_kernel(const float* __rest
   }
 }
 
+// the same for all (<= 4) scales in one launch: blockIdx.y = scale (three ~6 us launches, two of them on a side stream,
+// become one: the rows of every scale are final as soon as the loss gradient is)
+struct HeadGradPackBatch {
+  float* dO[4];
+  int D[4], H[4], W[4], prior_off[4];
+};
+__global__ __launch_bounds__(256) void head_grad_pack_batch_kernel(const float* __restrict__ dlocs,
+                                                                   const float* __restrict__ dscores, HeadGradPackBatch b,
+                                                                   int N, int CO, int Ptot, int ncls, int co_total) {
+  const int k = blockIdx.y;
+  const int D = b.D[k], H = b.H[k], W = b.W[k], prior_off = b.prior_off[k];
+  float* __restrict__ dO_pad = b.dO[k];
+  const int S = D * H * W, Hp = H + 2, Wp = W + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Wp;
+  const int total = N * CO * S;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int P = i % S, co = (i / S) % CO, n = i / (S * CO);
+    float v = 0.f;
+    if (co < 12) v = dlocs[((size_t)n * Ptot + prior_off) * 6 + (size_t)P * 12 + co];
+    else if (co < co_total) v = dscores[((size_t)n * Ptot + prior_off) * ncls + (size_t)P * 2 * ncls + co - 12];
+    const int w = P % W, h = (P / W) % H, d = P / (W * H);
+    dO_pad[((size_t)n * CO + co) * volp + ((size_t)(d + 1) * Hp + h + 1) * Wp + w + 1] = v;
+  }
+}
+
 // g_a (N, C, S) = conv_transpose(dO, W).  grid (ceil(S/32), C/64, N); wave -> 16 input channels x 32 positions
 template <int MT, bool BF16OUT = false>
 __global__ __launch_bounds__(256) void head_bwd_data_kernel(const float* __restrict__ dO_pad,
@@ -1084,6 +1109,25 @@ int msl_head_grad_pack(const float* dlocs, const float* dscores, float* dO_pad, 
   hipLaunchKernelGGL(head_grad_pack_kernel, dim3(std::min(msl::cdiv(total, 256), 2048)), dim3(256), 0,
                      (hipStream_t)stream, dlocs, dscores, dO_pad, N, D, H, W, CO, Ptot, prior_off, ncls,
                      12 + 2 * ncls);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// msl_head_grad_pack for all (n <= 4) scales in one launch; dO_pad / D / H / W / prior_off: host arrays of n entries
+int msl_head_grad_pack_batch(const float* dlocs, const float* dscores, float* const* dO_pad, const int* D, const int* H,
+                             const int* W, const int* prior_off, int n, int N, int Ptot, int ncls, void* stream) {
+  if (n < 1 || n > 4 || N <= 0 || head_mt(ncls) > 2) return MSL_ERR_ARG;
+  const int MT = head_mt(ncls), CO = 16 * MT;
+  HeadGradPackBatch b;
+  int smax = 0;
+  for (int k = 0; k < 4; ++k) {
+    const int j = k < n ? k : 0;
+    if (!dO_pad[j] || D[j] <= 0 || H[j] <= 0 || W[j] <= 0) return MSL_ERR_ARG;
+    b.dO[k] = dO_pad[j]; b.D[k] = D[j]; b.H[k] = H[j]; b.W[k] = W[j]; b.prior_off[k] = prior_off[j];
+    smax = std::max(smax, D[j] * H[j] * W[j]);
+  }
+  hipLaunchKernelGGL(head_grad_pack_batch_kernel, dim3(std::min(msl::cdiv(N * CO * smax, 256), 1024), n), dim3(256), 0,
+                     (hipStream_t)stream, dlocs, dscores, b, N, CO, Ptot, ncls, 12 + 2 * ncls);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -820,16 +820,14 @@ __global__ __launch_bounds__(256) void pw_bwd_weight_kernel(const float* __restr
 // workgroup: tail layers, 256 positions) or into its slab of a [nslabs][Cout][Cin] workspace that the batched gradient
 // reduction (optim.hip: grad_reduce_batch_kernel) sums in slab order.  No float atomics: run-to-run bit-identical.
 template <int MT, bool AFFINE>
-__global__ __launch_bounds__(256) void pw_bww_wave_kernel(const float* __restrict__ dY, const float* __restrict__ Z,
-                                                          const float* __restrict__ in_scale,
-                                                          const float* __restrict__ in_shift, float* __restrict__ out,
-                                                          int Cout, int Cin, int S, int chunks_per_img, int total_chunks,
-                                                          int chunks_per_block) {
+__device__ __forceinline__ void pw_bww_wave_body(const float* __restrict__ dY, const float* __restrict__ Z,
+                                                 const float* __restrict__ in_scale, const float* __restrict__ in_shift,
+                                                 float* __restrict__ out, int Cout, int Cin, int S, int chunks_per_img,
+                                                 int total_chunks, int chunks_per_block, int ks, int tile) {
   __shared__ __align__(16) float red[4 * MT * 1024];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, h = lane >> 5, c = lane & 31;
-  const int ks = blockIdx.x;
   const int tiles_n = Cin / 32;
-  const int tm = blockIdx.y / tiles_n, tn = blockIdx.y % tiles_n;
+  const int tm = tile / tiles_n, tn = tile % tiles_n;
   const int m0 = tm * 32 * MT, n0 = tn * 32;
   const int ch_lo = ks * chunks_per_block, ch_hi = min(total_chunks, ch_lo + chunks_per_block);
   const int mine = max(0, (ch_hi - ch_lo - wv + 3) / 4);  // chunks ch_lo + wv, + 4, ...
@@ -906,6 +904,43 @@ __global__ __launch_bounds__(256) void pw_bww_wave_kernel(const float* __restric
     }
     *reinterpret_cast<float4*>(dst + (size_t)(m0 + row) * Cin + n0 + col) = v;
   }
+}
+
+template <int MT, bool AFFINE>
+__global__ __launch_bounds__(256) void pw_bww_wave_kernel(const float* __restrict__ dY, const float* __restrict__ Z,
+                                                          const float* __restrict__ in_scale,
+                                                          const float* __restrict__ in_shift, float* __restrict__ out,
+                                                          int Cout, int Cin, int S, int chunks_per_img, int total_chunks,
+                                                          int chunks_per_block) {
+  pw_bww_wave_body<MT, AFFINE>(dY, Z, in_scale, in_shift, out, Cout, Cin, S, chunks_per_img, total_chunks, chunks_per_block,
+                               blockIdx.x, blockIdx.y);
+}
+
+// The tail of the network (blocks 4-7 at 128^3: 2048 / 256 positions per batch) gives this kernel 64-256 workgroups of
+// two to eight chunks each: four launches of ~8 us that are all latency.  ONE launch runs up to four such layers side by
+// side: workgroup b belongs to the layer k with first[k] <= b < first[k+1] and is that layer's workgroup
+// (ks, tile) = ((b - first[k]) % ksplit[k], (b - first[k]) / ksplit[k]); same arithmetic, same slabs, same bits.
+constexpr int PW_BWW_BATCH_MAX = 4;
+struct PwBwwBatch {
+  const float* dY[PW_BWW_BATCH_MAX];
+  const float* Z[PW_BWW_BATCH_MAX];
+  const float* in_scale[PW_BWW_BATCH_MAX];
+  const float* in_shift[PW_BWW_BATCH_MAX];
+  float* out[PW_BWW_BATCH_MAX];
+  int Cout[PW_BWW_BATCH_MAX], Cin[PW_BWW_BATCH_MAX], S[PW_BWW_BATCH_MAX], chunks_per_img[PW_BWW_BATCH_MAX],
+      total_chunks[PW_BWW_BATCH_MAX], chunks_per_block[PW_BWW_BATCH_MAX], ksplit[PW_BWW_BATCH_MAX],
+      first[PW_BWW_BATCH_MAX + 1];
+};
+
+__global__ __launch_bounds__(256) void pw_bww_wave_batch_kernel(PwBwwBatch b, int n) {
+  int k = 0;
+#pragma unroll
+  for (int j = 1; j < PW_BWW_BATCH_MAX; ++j)
+    if (j < n && (int)blockIdx.x >= b.first[j]) k = j;
+  const int local = blockIdx.x - b.first[k];
+  pw_bww_wave_body<2, true>(b.dY[k], b.Z[k], b.in_scale[k], b.in_shift[k], b.out[k], b.Cout[k], b.Cin[k], b.S[k],
+                            b.chunks_per_img[k], b.total_chunks[k], b.chunks_per_block[k], local % b.ksplit[k],
+                            local / b.ksplit[k]);
 }
 
 struct BwwWavePlan {
@@ -1123,6 +1158,41 @@ int msl_pwconv_bwd_weight_slabs(const float* dy, const float* z, const float* in
     if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<32, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
     else hipLaunchKernelGGL((pw_bwd_weight_kernel<32, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
   }
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// 1 when msl_pwconv_bwd_weight_slabs_batch takes this shape (the wave-autonomous form with 64-row tiles), else 0
+int msl_pwconv_bwd_weight_batchable(int N, int Cin, int Cout, int S) {
+  BwwWavePlan wp;
+  return (N > 0 && S > 0 && bww_wave_plan(N, Cin, Cout, S, wp) && wp.mt == 2) ? 1 : 0;
+}
+
+// msl_pwconv_bwd_weight_slabs for n <= 4 layers in ONE launch (host arrays of n entries each; every layer must be
+// msl_pwconv_bwd_weight_batchable and carries its input affine).  out[k]: as msl_pwconv_bwd_weight_slabs for layer k.
+int msl_pwconv_bwd_weight_slabs_batch(const float* const* dy, const float* const* z, const float* const* in_scale,
+                                      const float* const* in_shift, float* const* out, const int* Cin, const int* Cout,
+                                      const int* S, int n, int N, void* stream) {
+  if (n < 1 || n > PW_BWW_BATCH_MAX || N <= 0) return MSL_ERR_ARG;
+  PwBwwBatch b;
+  int total = 0;
+  for (int k = 0; k < n; ++k) {
+    BwwWavePlan wp;
+    if (!dy[k] || !z[k] || !in_scale[k] || !in_shift[k] || !out[k]) return MSL_ERR_ARG;
+    if (S[k] <= 0 || !bww_wave_plan(N, Cin[k], Cout[k], S[k], wp) || wp.mt != 2) return MSL_ERR_UNSUPPORTED;
+    b.dY[k] = dy[k]; b.Z[k] = z[k]; b.in_scale[k] = in_scale[k]; b.in_shift[k] = in_shift[k]; b.out[k] = out[k];
+    b.Cout[k] = Cout[k]; b.Cin[k] = Cin[k]; b.S[k] = S[k];
+    b.chunks_per_img[k] = wp.chunks_per_img; b.total_chunks[k] = wp.total_chunks;
+    b.chunks_per_block[k] = wp.chunks_per_block; b.ksplit[k] = wp.ksplit;
+    b.first[k] = total;
+    total += wp.ksplit * wp.tiles;
+  }
+  for (int k = n; k <= PW_BWW_BATCH_MAX; ++k) b.first[k] = total;
+  for (int k = n; k < PW_BWW_BATCH_MAX; ++k) {
+    b.dY[k] = b.Z[k] = b.in_scale[k] = b.in_shift[k] = nullptr; b.out[k] = nullptr;
+    b.Cout[k] = b.Cin[k] = b.S[k] = b.chunks_per_img[k] = b.total_chunks[k] = b.chunks_per_block[k] = 0; b.ksplit[k] = 1;
+  }
+  hipLaunchKernelGGL(pw_bww_wave_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b, n);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -265,6 +265,13 @@ class Engine:
         # the weight gradients of block i are enqueued after the chain launches of block i - wgrad_lag (host enqueue order
         # only; on the device they wait for their events): a larger lag keeps the dependency chain's queue ahead of the GPU
         self.wgrad_lag = int(os.environ.get("MSL_WGRAD_LAG", "1"))
+        # pointwise weight gradients of the tail blocks (<= 4096 positions per batch: 64-256 workgroups of a few chunks,
+        # launches that are all latency) in ONE launch, issued when the last of them has its dL/dy (single process only:
+        # a data-parallel step completes block 7's gradient bucket before block 4 is reached)
+        self.batch_tail_pw = os.environ.get("MSL_PW_BWW_BATCH", "1") == "1"
+        # (dL/dlocs, dL/dscores) -> the zero-haloed head gradient images of ALL scales in one launch on the chain, in front of
+        # the fork to the heads stream (was one ~6 us launch per scale, two of them on the heads stream)
+        self.batch_head_gpack = os.environ.get("MSL_HEAD_GPACK_BATCH", "1") == "1"
         e = os.environ.get("MSL_WGRAD_ON_HEADS")
         self.wgrad_on_heads = None if e is None else {int(v) for v in e.split(",") if v.strip()}
         # default: fold only the BatchNorms with at most this many partials per channel (MSL_FOLD_NP_MAX).  Round 2 A/B at
@@ -783,8 +790,9 @@ class Engine:
         def head(f, s_data, s_weight, done=None):
             C = specs[f]["cout"]
             D, H, W = pl.dims[f]
-            self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P,
-                    pl.prior_off[f], ncls, s_data)
+            if not packed:
+                self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), N, D, H, W, pl.P,
+                        pl.prior_off[f], ncls, s_data)
             self._k(f"head_bwd{f}", "msl_head_conv_bwd_data_bf16", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), N, C, D, H, W,
                     ncls, s_data)
             if done is not None:
@@ -795,6 +803,9 @@ class Engine:
                     ptr(pl.head_ws[f]), N, C, D, H, W, ncls, s_weight)
 
         side_feats = [f for f in pl.feat_ids if f != last] if ms else []
+        packed = bool(side_feats) and self.batch_head_gpack
+        if packed:
+            self._head_gpack_batch(pl, dlocs, dscores, st)
         if side_feats:
             self._fork(pl, "bwd_loss_ready", st, stH)
         head(last, st, stW)  # its data gradient starts the chain
@@ -906,6 +917,18 @@ class Engine:
             return
         _lib.call("msl_bn_finalize_batch", ptr(pl.bn_table), pl.bn_table_n, pl.bn_table_channels, st, tag="bn_finalize_all")
 
+    def _pw_bww_batch(self, pl, rows, N, st):
+        """msl_pwconv_bwd_weight_slabs for several tail blocks in one launch; rows = (dy, z, scale, shift, out, cin, cout, S)."""
+        import ctypes
+        key = tuple(rows)
+        if getattr(pl, "pwb_key", None) != key:
+            n = len(rows)
+            P, I = ctypes.c_void_p * n, ctypes.c_int * n
+            pl.pwb_args = tuple(P(*[r[c] for r in rows]) for c in range(5)) + tuple(I(*[r[c] for r in rows]) for c in range(5, 8))
+            pl.pwb_key = key
+        a = pl.pwb_args  # host arrays: kept alive by the plan (a recorded launch program points at them)
+        self._k("pw_bww_tail", "msl_pwconv_bwd_weight_slabs_batch", *[ctypes.addressof(x) for x in a], len(rows), N, st)
+
     def _pack_head_weights(self, pl, st):
         import ctypes
         m = self.model
@@ -969,15 +992,30 @@ class Engine:
         self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_apply", ptr(g), ptr(y), ptr(vec[0]), ptr(vec[1]), ptr(vec[2]), ptr(vec[3]),
                   ptr(vec[4]), ptr(vec[5]), ptr(g), N, C, S, st)
 
-    def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None, data=True, weight=True):
+    def _head_gpack_batch(self, pl, dlocs, dscores, st):
+        """msl_head_grad_pack of every scale in one launch."""
+        import ctypes
+        key = (ptr(dlocs), ptr(dscores)) + tuple(ptr(pl.dO[f]) for f in pl.feat_ids)
+        if getattr(pl, "gpack_key", None) != key:
+            n = len(pl.feat_ids)
+            I = ctypes.c_int * n
+            pl.gpack_args = ((ctypes.c_void_p * n)(*[ptr(pl.dO[f]) for f in pl.feat_ids]),) + tuple(
+                I(*[pl.dims[f][a] for f in pl.feat_ids]) for a in range(3)) + (I(*[pl.prior_off[f] for f in pl.feat_ids]),)
+            pl.gpack_key = key
+        a = pl.gpack_args  # host arrays: kept alive by the plan (a recorded launch program points at them)
+        self._k("head_gpack_all", "msl_head_grad_pack_batch", ptr(dlocs), ptr(dscores), *[ctypes.addressof(x) for x in a],
+                len(pl.feat_ids), pl.N, pl.P, self.model.n_classes, st)
+
+    def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None, data=True, weight=True, packed=False):
         m, gv, ncls = self.model, self.arena.grad_views, self.model.n_classes
         k = pl.feat_ids.index(f)
         C = self.layer_specs[f]["cout"]
         D, H, W = pl.dims[f]
         pre = f"pred_convs.loc_convs.{k}", f"pred_convs.cl_convs.{k}"
         if data:
-            self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), pl.N, D, H, W, pl.P,
-                    pl.prior_off[f], ncls, st)
+            if not packed:
+                self._k(f"head_gpack{f}", "msl_head_grad_pack", ptr(dlocs), ptr(dscores), ptr(pl.dO[f]), pl.N, D, H, W, pl.P,
+                        pl.prior_off[f], ncls, st)
             self._k(f"head_bwd{f}", "msl_head_conv_bwd_data", ptr(pl.dO[f]), ptr(pl.Wb[f]), ptr(pl.g_y[f]), pl.N, C, D, H, W, ncls, st)
             if data_done_event is not None:  # the activation-gradient chain only waits for the data gradient
                 _lib.call("msl_event_record", data_done_event, st, tag="event")
@@ -1055,23 +1093,34 @@ class Engine:
         # the chain reaches their feature map, so they run on the heads stream beside blocks 7..4
         last = len(specs) - 1
         side_feats = [f for f in pl.feat_ids if f != last] if ms else []
+        packed = bool(side_feats) and self.batch_head_gpack
+        if packed:
+            self._head_gpack_batch(pl, dlocs, dscores, st)
         if side_feats:
             self._fork(pl, "bwd_loss_ready", st, stH)
         L = _lib.load()
         pre_np = None  # set when the producer of the next activation gradient also produced its BatchNorm partials
         pending = []  # side-stream launches, issued one layer late so that the chain's launches always go first
         sinks = []    # (layer, closure) of the weight-gradient launches still to be issued
+        tail = []     # blocks whose pointwise weight gradients share one launch (deepest first), and their arguments
+        if ms and not groups and self.batch_tail_pw:
+            for i in range(last, 0, -1):
+                D_, H_, W_ = pl.dims[i]
+                if N * D_ * H_ * W_ <= 4096 and L.msl_pwconv_bwd_weight_batchable(N, specs[i]["cin"], specs[i]["cout"], D_ * H_ * W_) == 1:
+                    tail.append(i)
+            tail = tail[:4] if len(tail) >= 2 else []
+        tail_args = []
         for f in pl.feat_ids:  # the chain's own scale first: its data gradient starts the backward chain
             if f not in side_feats:
                 if ms:
-                    self._head_backward(pl, f, dlocs, dscores, st, weight=False)
+                    self._head_backward(pl, f, dlocs, dscores, st, weight=False, packed=packed)
                     ev = self._record(pl, f"head_dO{f}", st)
                     pending.append(lambda f=f, ev=ev: (self._wait(stW, ev),
                                                        self._head_backward(pl, f, dlocs, dscores, stW, data=False)))
                 else:
-                    self._head_backward(pl, f, dlocs, dscores, st)
+                    self._head_backward(pl, f, dlocs, dscores, st, packed=packed)
         for f in reversed(side_feats):  # the deeper scale is needed first
-            pending.append(lambda f=f: self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}")))
+            pending.append(lambda f=f: self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}"), packed=packed))
         if wanted is not None and "heads" in wanted:
             for fn in pending:
                 fn()
@@ -1135,8 +1184,14 @@ class Engine:
                     self._wait(sX, ev_dy if ev_dy is not None else ev_dz)
                 # partial sums only: slabs / fp64 partials stay in this layer's own buffers until Engine._grad_reduce
                 out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
-                self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
-                        ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, sX)
+                if i in tail:
+                    tail_args.append((ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(out), sp["cin"],
+                                      sp["cout"], S))
+                    if i == tail[-1]:  # the shallowest: every dL/dy of the group is final (same chain, earlier)
+                        self._pw_bww_batch(pl, tail_args, N, sX)
+                else:
+                    self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
+                            ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, sX)
                 if ms and ev_dy is not None:
                     self._wait(sX, ev_dz)
                 if fused_stem:

@@ -357,6 +357,42 @@ def test_pw_fwd_bwd(N, Cin, Cout, S):
         close(dw2, torch.einsum("nos,ncs->oc", dy.double(), z.double()).float(), 1e-4, atol, "pw bwd weight, no affine")
 
 
+def test_pw_bww_batch_is_the_single_launches_bit_for_bit():
+    """msl_pwconv_bwd_weight_slabs_batch (the tail blocks' pointwise weight gradients in one launch) writes exactly the
+    slabs of the per-layer launches: the 128^3 x 4 shapes of blocks 7..4 (two with a position split, two without)."""
+    import ctypes
+    L = _lib.load()
+    N = 4
+    shapes = [(512, 512, 64), (256, 512, 64), (256, 256, 512), (128, 256, 512)]  # (Cin, Cout, S)
+    rows, single = [], []
+    for q, (Cin, Cout, S) in enumerate(shapes):
+        assert L.msl_pwconv_bwd_weight_batchable(N, Cin, Cout, S) == 1
+        dy, z = K(rnd(N, Cout, S, seed=40 + q)), K(rnd(N, Cin, S, seed=50 + q))
+        sc, sh = K(rnd(Cin, seed=60 + q).abs() + 0.5), K(rnd(Cin, seed=70 + q, scale=0.3))
+        ns = L.msl_pwconv_bwd_weight_nslabs(N, Cin, Cout, S)
+        ref = torch.full((ns, Cout, Cin), float("nan"), device=DEV)
+        _lib.call("msl_pwconv_bwd_weight_slabs", ptr(dy), ptr(z), ptr(sc), ptr(sh), ptr(ref), N, Cin, Cout, S, st())
+        out = torch.full((ns, Cout, Cin), float("nan"), device=DEV)
+        rows.append((dy, z, sc, sh, out, Cin, Cout, S))
+        single.append(ref)
+    for n in (4, 2):  # the whole group, and a shorter one
+        for r in rows:
+            r[4].fill_(float("nan"))
+        P, I = ctypes.c_void_p * n, ctypes.c_int * n
+        arrs = [P(*[ptr(r[c]) for r in rows[:n]]) for c in range(5)] + [I(*[r[c] for r in rows[:n]]) for c in range(5, 8)]
+        _lib.call("msl_pwconv_bwd_weight_slabs_batch", *[ctypes.addressof(a) for a in arrs], n, N, st())
+        torch.cuda.synchronize()
+        for q in range(n):
+            assert torch.equal(rows[q][4], single[q]), f"layer {q} of a batch of {n}"
+    assert L.msl_pwconv_bwd_weight_batchable(N, 32, 96, 96) == 0  # 32-row tiles: not in the batch form
+    bad = (ctypes.c_int * 1)(96)
+    one = [(ctypes.c_void_p * 1)(ptr(rows[0][c])) for c in range(5)]
+    rc = L.msl_pwconv_bwd_weight_slabs_batch(*[ctypes.addressof(a) for a in one], ctypes.addressof((ctypes.c_int * 1)(32)),
+                                             ctypes.addressof(bad), ctypes.addressof((ctypes.c_int * 1)(96)), 1, 1, st())
+    assert rc != 0
+
+
+
 def grad_reduce(rows):
     """rows of (kind, src, dst, dst2, nslabs, count, stride, p0, p1, p2) -> one msl_grad_reduce_batch launch."""
     import ctypes
@@ -533,6 +569,35 @@ def test_heads_fwd_bwd(N, C, dims, ncls):
     close(gcw, cw.grad, 1e-4, atol_w, "head dW cls")
     close(glb, lb.grad, 1e-4, 1e-4, "head db loc")
     close(gcb, cb.grad, 1e-4, 1e-4, "head db cls")
+
+
+@pytest.mark.parametrize("ncls", [2, 3])
+def test_head_grad_pack_batch_is_the_single_launches_bit_for_bit(ncls):
+    """msl_head_grad_pack_batch (every scale's head gradient image in one launch) == one msl_head_grad_pack per scale."""
+    import ctypes
+    L = _lib.load()
+    N = 3
+    dims = [(16, 16, 16), (8, 8, 8), (4, 4, 4), (5, 6, 7)]
+    offs, Ptot = [], 3
+    for d in dims:
+        offs.append(Ptot)
+        Ptot += 2 * d[0] * d[1] * d[2]
+    Ptot += 5
+    dl, dc = K(rnd(N, Ptot, 6, seed=80)), K(rnd(N, Ptot, ncls, seed=81))
+    mt16 = 16 * ((12 + 2 * ncls + 15) // 16)
+    ref = [torch.zeros((N, mt16) + tuple(x + 2 for x in d), device=DEV) for d in dims]
+    for r, d, o in zip(ref, dims, offs):
+        _lib.call("msl_head_grad_pack", ptr(dl), ptr(dc), ptr(r), N, *d, Ptot, o, ncls, st())
+    for n in (4, 3, 1):
+        out = [torch.zeros_like(r) for r in ref[:n]]
+        I = ctypes.c_int * n
+        arrs = [(ctypes.c_void_p * n)(*[ptr(o) for o in out])] + [I(*[d[a] for d in dims[:n]]) for a in range(3)] + [I(*offs[:n])]
+        _lib.call("msl_head_grad_pack_batch", ptr(dl), ptr(dc), *[ctypes.addressof(a) for a in arrs], n, N, Ptot, ncls, st())
+        torch.cuda.synchronize()
+        for q in range(n):
+            assert torch.equal(out[q], ref[q]), f"scale {q} of {n}"
+    assert L.msl_head_grad_pack_batch(ptr(dl), ptr(dc), ctypes.addressof(arrs[0]), ctypes.addressof(arrs[1]), ctypes.addressof(arrs[2]),
+                                      ctypes.addressof(arrs[3]), ctypes.addressof(arrs[4]), 5, N, Ptot, ncls, st()) != 0
 
 
 # ------------------------------------------------------------------------------------------------- adam
