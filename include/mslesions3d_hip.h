@@ -191,6 +191,10 @@ int msl_dwconv_fwd_bf16_num_partials(int N, int C, int D, int H, int W, int stri
 /* the register-marching wave kernels of the fp32 path on bf16 storage (square power-of-two planes; MSL_ERR_UNSUPPORTED
  * otherwise - msl_dwconv_*_bf16 try these first and fall back to the LDS-tiled any-shape kernels) */
 int msl_dwconv_wave_num_partials(int N, int C, int D, int H, int W, int stride);
+/* 1 when a statistics-free (eval-mode) forward of this shape runs on the register-marching rows kernels (W % 4 == 0 planes that
+ * are not powers of two, e.g. the 96^2 ... 12^2 planes of a 192^3 volume): fp32 inside msl_dwconv_fwd, bf16 inside
+ * msl_dwconv_fwd_wave_bf16 / msl_dwconv_fwd_bf16 when partials == NULL.  mobilenet.py:37-39 */
+int msl_dwconv_fwd_eval_rows_ok(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                              double* partials, int N, int C, int D, int H, int W, int stride, int flip, int accumulate,
                              void* stream);

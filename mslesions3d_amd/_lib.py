@@ -78,6 +78,7 @@ _SIGNATURES = {
     "msl_stem_conv_fwd_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_bf16_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_wave_num_partials": (_I, [_I] * 6),
+    "msl_dwconv_fwd_eval_rows_ok": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd_wave_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_data_s2_patch_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_wave_bf16_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

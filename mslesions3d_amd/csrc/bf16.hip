@@ -11,6 +11,7 @@
 
 // dwconv.hip: the register-marching wave kernels on bf16 storage (square power-of-two planes)
 extern "C" int msl_dwconv_wave_num_partials(int N, int C, int D, int H, int W, int stride);
+extern "C" int msl_dwconv_fwd_eval_rows_ok(int N, int C, int D, int H, int W, int stride);
 extern "C" int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                                         double* partials, int N, int C, int D, int H, int W, int stride, int flip,
                                         int accumulate, void* stream);
@@ -831,7 +832,8 @@ int msl_dwconv_fwd_bf16_num_partials(int N, int C, int D, int H, int W, int stri
 int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                         double* partials, int N, int C, int D, int H, int W, int stride, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
-  if (dw_bf16_use_wave() && msl_dwconv_wave_num_partials(N, C, D, H, W, stride) > 0)
+  if (dw_bf16_use_wave() && (msl_dwconv_wave_num_partials(N, C, D, H, W, stride) > 0 ||
+                             (!partials && msl_dwconv_fwd_eval_rows_ok(N, C, D, H, W, stride) == 1)))
     return msl_dwconv_fwd_wave_bf16(x, in_scale, in_shift, w, y, partials, N, C, D, H, W, stride, 0, 0, stream);
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   const int tiles_d = msl::cdiv(OD, DW_TD), tiles_h = msl::cdiv(OH, DW_TH), tiles_w = msl::cdiv(OW, DW_TW);

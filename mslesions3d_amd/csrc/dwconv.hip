@@ -902,6 +902,195 @@ __global__ __launch_bounds__((s2_wave_block<LOGW4, LOGOH>())) void dw_s2_wave_ke
   }
 }
 
+// Stride-2 register-marching kernel for planes of ANY width W % 4 == 0 and even H, forward WITHOUT statistics (eval-mode
+// inference: the 96^2 / 48^2 / 24^2 / 12^2 planes of a 192^3 volume, which the power-of-two kernels above do not take and
+// the LDS-streamed kernel moves at 2.2 TB/s).  Same cell = (output row, two adjacent outputs) per lane and the same
+// arithmetic order as dw_s2_wave_kernel; the differences: a wave owns RPW = floor(64 / W4) WHOLE output rows of one plane
+// slab (W4 = W / 4 lanes per row; the remaining lanes idle: 48 of 64 at W = 96), so that a lane's left neighbour is
+// always the previous lane of the same wave - fetched with a wave-wide DPP shift (wave_shr:1), since rows of 24 lanes
+// straddle the 16-lane DPP rows - and the geometry is run-time (one integer division per lane, outside the plane loop).
+template <int SL, typename T>
+__global__ __launch_bounds__(256) void dw_s2_rows_eval_kernel(const T* __restrict__ x, const float* __restrict__ in_scale,
+                                                              const float* __restrict__ in_shift,
+                                                              const float* __restrict__ w, T* __restrict__ y, int C, int D,
+                                                              int H, int W, int OD, int nslabs, int RPW, int RG,
+                                                              int total_waves) {
+  constexpr int NPL = 2 * SL + 1;
+  const int W4 = W >> 2, OH = H >> 1, OW = W >> 1, HW = H * W, OHW = OH * OW;
+  const int lane = threadIdx.x & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
+  if (gw >= total_waves) return;  // whole wave
+  const int rg = gw % RG, t0 = gw / RG;  // the row groups of one plane slab are neighbours (they share halo rows)
+  const int slab = t0 % nslabs, vg = t0 / nslabs;
+  const int n = vg / C, c = vg % C;  // wave-uniform: taps and affine are scalar
+  const int lr = lane / W4, w4 = lane - lr * W4;
+  const int oh_raw = rg * RPW + lr;
+  const bool live = lr < RPW && oh_raw < OH;
+  const int oh = live ? oh_raw : 0;     // idle lanes repeat a valid cell's loads and store nothing
+  const int od0 = slab * SL;
+  const bool up_ok = oh > 0, lf_ok = w4 > 0;
+
+  const T* xc = x + (size_t)(n * C + c) * D * HW + (live ? w4 : 0) * 4;
+  const int row_m = (up_ok ? 2 * oh - 1 : 0) * W, row_0 = 2 * oh * W;
+  float4 pv[NPL][3];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = min(max(2 * od0 - 1 + i, 0), D - 1);
+    const T* xp = xc + (size_t)p * HW;
+    pv[i][0] = ld4(xp + row_m);
+    pv[i][1] = ld4(xp + row_0);
+    pv[i][2] = ld4(xp + row_0 + W);
+  }
+  float wk[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = w[(size_t)c * 27 + k];
+  const bool affine = in_scale != nullptr;
+  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) msl::pin(pv[i][r]);
+
+  float acc[SL][2];
+#pragma unroll
+  for (int o = 0; o < SL; ++o) acc[o][0] = acc[o][1] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = 2 * od0 - 1 + i;
+    if (p < 0 || p >= D) continue;  // wave-uniform
+    float Tr[3][5];  // Tr[kh][0..4] = columns 4*w4-1 .. 4*w4+3 of input row 2*oh-1+kh
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float4 m = pv[i][r];
+      if (affine) {
+        m.x = msl::act(m.x, sc, sh); m.y = msl::act(m.y, sc, sh);
+        m.z = msl::act(m.z, sc, sh); m.w = msl::act(m.w, sc, sh);
+      }
+      if (r == 0) {  // the row above the first output row is padding
+        m.x = up_ok ? m.x : 0.f; m.y = up_ok ? m.y : 0.f; m.z = up_ok ? m.z : 0.f; m.w = up_ok ? m.w : 0.f;
+      }
+      Tr[r][1] = m.x; Tr[r][2] = m.y; Tr[r][3] = m.z; Tr[r][4] = m.w;
+      const float l = msl::dpp_mov<0x138>(m.w);  // wave_shr:1 - the previous lane's last column
+      Tr[r][0] = lf_ok ? l : 0.f;
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      if ((i - kd) % 2 != 0 || i - kd < 0) continue;
+      const int o = (i - kd) / 2;
+      if (o >= SL) continue;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float ww = wk[kd * 9 + kh * 3 + kw];
+          acc[o][0] = fmaf(ww, Tr[kh][kw], acc[o][0]);
+          acc[o][1] = fmaf(ww, Tr[kh][kw + 2], acc[o][1]);
+        }
+    }
+  }
+  if (!live) return;
+  T* yc = y + (size_t)(n * C + c) * OD * OHW + oh * OW + 2 * w4;
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    const int od = od0 + o;
+    if (od >= OD) continue;  // wave-uniform (ragged last slab)
+    st2(yc + (size_t)od * OHW, make_float2(acc[o][0], acc[o][1]));
+  }
+}
+
+// Stride-1 sibling of dw_s2_rows_eval_kernel (the 24^2 / 12^2 planes of a 192^3 volume): a lane owns output row h x four
+// adjacent outputs and loads the three input rows h-1, h, h+1 of its own float4 column (two of the three are cache hits),
+// so the only cross-lane values are the columns left and right of it (wave_shr:1 / wave_shl:1).  Tap order as
+// dw_s1_wave_kernel.  W % 4 == 0, any H and D; forward without statistics.
+template <int SL, typename T>
+__global__ __launch_bounds__(256) void dw_s1_rows_eval_kernel(const T* __restrict__ x, const float* __restrict__ in_scale,
+                                                              const float* __restrict__ in_shift,
+                                                              const float* __restrict__ w, T* __restrict__ y, int C, int D,
+                                                              int H, int W, int nslabs, int RPW, int RG, int total_waves) {
+  constexpr int NPL = SL + 2;
+  const int W4 = W >> 2, HW = H * W;
+  const int lane = threadIdx.x & 63;
+  const int gw = __builtin_amdgcn_readfirstlane(xcd_remap(blockIdx.x, gridDim.x) * 4 + (threadIdx.x >> 6));
+  if (gw >= total_waves) return;  // whole wave
+  const int rg = gw % RG, t0 = gw / RG;
+  const int slab = t0 % nslabs, vg = t0 / nslabs;
+  const int n = vg / C, c = vg % C;  // wave-uniform
+  const int lr = lane / W4, w4 = lane - lr * W4;
+  const int h_raw = rg * RPW + lr;
+  const bool live = lr < RPW && h_raw < H;
+  const int h = live ? h_raw : 0;
+  const int od0 = slab * SL;
+  const bool up_ok = h > 0, dn_ok = h < H - 1, lf_ok = w4 > 0, rt_ok = w4 < W4 - 1;
+
+  const T* xc = x + (size_t)(n * C + c) * D * HW + (live ? w4 : 0) * 4;
+  const int row_m = (up_ok ? h - 1 : h) * W, row_0 = h * W, row_p = (dn_ok ? h + 1 : h) * W;
+  float4 pv[NPL][3];
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = min(max(od0 - 1 + i, 0), D - 1);
+    const T* xp = xc + (size_t)p * HW;
+    pv[i][0] = ld4(xp + row_m);
+    pv[i][1] = ld4(xp + row_0);
+    pv[i][2] = ld4(xp + row_p);
+  }
+  float wk[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) wk[k] = w[(size_t)c * 27 + k];
+  const bool affine = in_scale != nullptr;
+  const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i)
+#pragma unroll
+    for (int r = 0; r < 3; ++r) msl::pin(pv[i][r]);
+
+  float acc[SL][4];
+#pragma unroll
+  for (int o = 0; o < SL; ++o)
+#pragma unroll
+    for (int v = 0; v < 4; ++v) acc[o][v] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NPL; ++i) {
+    const int p = od0 - 1 + i;
+    if (p < 0 || p >= D) continue;  // wave-uniform: a zero plane adds nothing
+    float R[3][6];  // R[kh][0..5] = columns 4*w4-1 .. 4*w4+4 of input row h-1+kh
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      float4 m = pv[i][r];
+      if (affine) {
+        m.x = msl::act(m.x, sc, sh); m.y = msl::act(m.y, sc, sh);
+        m.z = msl::act(m.z, sc, sh); m.w = msl::act(m.w, sc, sh);
+      }
+      const bool rok = r == 0 ? up_ok : r == 2 ? dn_ok : true;  // rows outside the plane are padding
+      m.x = rok ? m.x : 0.f; m.y = rok ? m.y : 0.f; m.z = rok ? m.z : 0.f; m.w = rok ? m.w : 0.f;
+      R[r][1] = m.x; R[r][2] = m.y; R[r][3] = m.z; R[r][4] = m.w;
+      const float l = msl::dpp_mov<0x138>(m.w), rr = msl::dpp_mov<0x130>(m.x);  // wave_shr:1 / wave_shl:1
+      R[r][0] = lf_ok ? l : 0.f;
+      R[r][5] = rt_ok ? rr : 0.f;
+    }
+#pragma unroll
+    for (int kd = 0; kd < 3; ++kd) {
+      const int o = i - kd;  // output plane od0 + o reads input plane od0 + o - 1 + kd
+      if (o < 0 || o >= SL) continue;
+#pragma unroll
+      for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+          const float ww = wk[kd * 9 + kh * 3 + kw];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) acc[o][v] = fmaf(ww, R[kh][v + kw], acc[o][v]);
+        }
+    }
+  }
+  if (!live) return;
+  T* yc = y + (size_t)(n * C + c) * D * HW + h * W + w4 * 4;
+#pragma unroll
+  for (int o = 0; o < SL; ++o) {
+    const int od = od0 + o;
+    if (od >= D) continue;  // wave-uniform (ragged last slab)
+    st4(yc + (size_t)od * HW, make_float4(acc[o][0], acc[o][1], acc[o][2], acc[o][3]));
+  }
+}
+
 // Weight gradient on the same register-marching layout (bwd-weight of the layers the two kernels above run forward):
 // dw[c][k] = sum over outputs of dy[o] * a[o*s - 1 + k].  The wave holds its input planes AND the dy planes of its
 // output slab in registers, every lane accumulates 27 tap sums over its cells, the lanes of a channel are then summed
@@ -1372,6 +1561,49 @@ void launch_wave_s2(const WavePlan& wp, const T* x, const float* in_scale, const
 #undef MSL_DW_WAVE2_SL
 }
 
+// eval-mode forward on dw_s2_rows_eval_kernel / dw_s1_rows_eval_kernel: no statistics, planes the power-of-two wave kernels do not take
+// (MSL_DW_ROWS_EVAL=0 sends them back to the LDS kernels)
+bool rows_eval_ok(int N, int C, int D, int H, int W, int stride) {
+  static const int on = getenv("MSL_DW_ROWS_EVAL") ? atoi(getenv("MSL_DW_ROWS_EVAL")) : 1;
+  if (!on || W % 4 != 0 || W < 8 || W > 256 || D < 2) return false;
+  if (stride == 2 && H % 2 != 0) return false;
+  if (make_wave_plan(N, C, D, H, W, stride).ok) return false;
+  const int OD = (D - 1) / stride + 1, SL = OD >= 8 ? 4 : OD >= 4 ? 2 : 1, RPW = 64 / (W / 4);
+  return (long long)N * C * msl::cdiv(OD, SL) * msl::cdiv(stride == 2 ? H / 2 : H, RPW) < (1ll << 30);
+}
+
+template <typename T>
+void launch_rows_eval(const T* x, const float* in_scale, const float* in_shift, const float* w, T* y, int N, int C, int D,
+                      int H, int W, int stride, hipStream_t st) {
+  if (stride == 1) {
+    const int SL = D >= 8 ? 4 : D >= 4 ? 2 : 1, nslabs = msl::cdiv(D, SL);
+    const int RPW = 64 / (W / 4), RG = msl::cdiv(H, RPW);
+    const int waves = N * C * nslabs * RG;
+    const dim3 grid(msl::cdiv(waves, 4)), block(256);
+    switch (SL) {
+      case 4: hipLaunchKernelGGL((dw_s1_rows_eval_kernel<4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
+                                 nslabs, RPW, RG, waves); break;
+      case 2: hipLaunchKernelGGL((dw_s1_rows_eval_kernel<2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
+                                 nslabs, RPW, RG, waves); break;
+      default: hipLaunchKernelGGL((dw_s1_rows_eval_kernel<1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
+                                  nslabs, RPW, RG, waves); break;
+    }
+    return;
+  }
+  const int OD = (D - 1) / 2 + 1, SL = OD >= 8 ? 4 : OD >= 4 ? 2 : 1, nslabs = msl::cdiv(OD, SL);
+  const int RPW = 64 / (W / 4), RG = msl::cdiv(H / 2, RPW);
+  const int waves = N * C * nslabs * RG;
+  const dim3 grid(msl::cdiv(waves, 4)), block(256);
+  switch (SL) {
+    case 4: hipLaunchKernelGGL((dw_s2_rows_eval_kernel<4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
+                               nslabs, RPW, RG, waves); break;
+    case 2: hipLaunchKernelGGL((dw_s2_rows_eval_kernel<2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
+                               nslabs, RPW, RG, waves); break;
+    default: hipLaunchKernelGGL((dw_s2_rows_eval_kernel<1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
+                                nslabs, RPW, RG, waves); break;
+  }
+}
+
 // weight gradient on the wave kernels (MSL_DW_WAVE_BWW=0 sends it back to the LDS-tiled / generic kernels)
 bool wave_bww_enabled() {
   static const int on = getenv("MSL_DW_WAVE_BWW") ? atoi(getenv("MSL_DW_WAVE_BWW")) : 1;
@@ -1457,6 +1689,12 @@ int msl_dwconv_wave_num_partials(int N, int C, int D, int H, int W, int stride) 
   return wp.ok ? N * wp.nslabs * (wp.wpp > 4 ? wp.wpp / 4 : 1) : MSL_ERR_UNSUPPORTED;
 }
 
+// 1 when a statistics-free (eval-mode) forward of this shape runs on dw_s2_rows_eval_kernel / dw_s1_rows_eval_kernel (fp32: inside
+// msl_dwconv_fwd; bf16: msl_dwconv_fwd_wave_bf16 with partials == NULL), else 0
+int msl_dwconv_fwd_eval_rows_ok(int N, int C, int D, int H, int W, int stride) {
+  return (N > 0 && C > 0 && D > 0 && H > 0 && W > 0 && rows_eval_ok(N, C, D, H, W, stride)) ? 1 : 0;
+}
+
 // x (N,C,D,H,W) bf16 raw (+ input affine) -> y bf16 raw (+ fp64 statistics partials [2][C][NP] from the fp32 accumulators);
 // flip: reversed taps (stride-1 bwd-data), accumulate: y += result
 int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
@@ -1464,6 +1702,12 @@ int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* 
                              void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
   const WavePlan wp = make_wave_plan(N, C, D, H, W, stride);
+  if (!wp.ok && !partials && !flip && !accumulate && rows_eval_ok(N, C, D, H, W, stride)) {  // eval-mode forward
+    launch_rows_eval(reinterpret_cast<const dwu16*>(x), in_scale, in_shift, w, reinterpret_cast<dwu16*>(y), N, C, D, H, W,
+                     stride, (hipStream_t)stream);
+    MSL_LAUNCH_CHECK();
+    return MSL_OK;
+  }
   if (!wp.ok || (stride == 2 && (flip || accumulate))) return MSL_ERR_UNSUPPORTED;
   if (stride == 1)
     launch_wave(wp, reinterpret_cast<const dwu16*>(x), in_scale, in_shift, w, reinterpret_cast<dwu16*>(y), partials, N, C, D, flip,
@@ -1603,6 +1847,11 @@ static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* i
     if (wp.ok) {
       if (stride == 2) launch_wave_s2(wp, x, in_scale, in_shift, w, y, partials, N, C, D, fold, st);
       else launch_wave(wp, x, in_scale, in_shift, w, y, partials, N, C, D, 0, 0, fold, st);
+      MSL_LAUNCH_CHECK();
+      return MSL_OK;
+    }
+    if (!partials && !fold.partials && rows_eval_ok(N, C, D, H, W, stride)) {  // eval-mode forward, no statistics
+      launch_rows_eval(x, in_scale, in_shift, w, y, N, C, D, H, W, stride, st);
       MSL_LAUNCH_CHECK();
       return MSL_OK;
     }

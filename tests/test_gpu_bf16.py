@@ -67,6 +67,24 @@ def test_dw_fwd_bf16(N, C, dims, stride, affine):
     close(p[1], (ref.double() ** 2).sum((0, 2, 3, 4)), 1e-4, 1e-3, "dw sumsq")
 
 
+@pytest.mark.parametrize("N,C,dims,stride", [(2, 8, (10, 96, 96), 2), (1, 16, (10, 48, 48), 2), (1, 4, (7, 24, 24), 2),
+                                             (1, 3, (5, 12, 12), 2), (1, 2, (6, 20, 40), 2), (2, 8, (9, 24, 24), 1),
+                                             (1, 16, (12, 12, 12), 1), (1, 3, (5, 7, 20), 1)])
+def test_dw_fwd_eval_rows_bf16(N, C, dims, stride):
+    """Statistics-free (eval-mode) forward on bf16 storage: the register-marching rows kernel for planes that are
+    not powers of two (partials == NULL selects it) against fp32 conv3d on the same bf16-rounded input."""
+    L = _lib.load()
+    assert L.msl_dwconv_fwd_eval_rows_ok(N, C, *dims, stride) == 1
+    x = bfr(rnd(N, C, *dims, seed=4))
+    w = rnd(C, 1, 3, 3, 3, seed=5, scale=0.4)
+    sc, sh = rnd(C, seed=6).abs() + 0.5, rnd(C, seed=7, scale=0.3)
+    a = torch.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    ref = F.conv3d(a, w, stride=stride, padding=1, groups=C)
+    y = torch.full(ref.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("msl_dwconv_fwd_bf16", ptr(K(x.to(torch.bfloat16))), ptr(K(sc)), ptr(K(sh)), ptr(K(w)), ptr(y), None, N, C, *dims, stride, st())
+    close(y.float(), ref, 2 * BF_EPS, 1e-5, "dw fwd bf16 (eval rows)")
+
+
 @pytest.mark.parametrize("N,Cin,Cout,S", [(2, 32, 64, 1000), (1, 64, 128, 64), (2, 128, 128, 130), (1, 512, 512, 8),
                                           (1, 256, 512, 27), (2, 128, 256, 1728), (1, 32, 96, 200),
                                           # whole 64-position tiles: the pipelined transposed-read kernel (K chunks of 32 / 64 /

@@ -133,6 +133,36 @@ def test_dw_fwd(N, C, dims, stride, variant, affine):
             close(q, (ref.double() ** 2).sum((0, 2, 3, 4)), 1e-5, 1e-3, "dw sumsq")
 
 
+@pytest.mark.parametrize("N,C,dims,stride", [(2, 8, (10, 96, 96), 2), (1, 16, (10, 48, 48), 2), (1, 4, (7, 24, 24), 2),
+                                             (1, 3, (5, 12, 12), 2), (1, 2, (6, 20, 40), 2), (2, 3, (2, 6, 8), 2),
+                                             (1, 2, (17, 10, 256), 2), (1, 5, (9, 96, 24), 2),
+                                             (2, 8, (9, 24, 24), 1), (1, 16, (12, 12, 12), 1), (1, 3, (5, 7, 20), 1),
+                                             (1, 2, (3, 33, 96), 1), (2, 4, (2, 5, 8), 1), (1, 2, (6, 9, 256), 1)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_dw_fwd_eval_rows(N, C, dims, stride, affine):
+    """Statistics-free (eval-mode) forward on dw_s2_rows_eval_kernel / dw_s1_rows_eval_kernel: planes that are not powers of
+    two (the 192^3 inference maps 96^2 ... 12^2), rows of 24 / 12 / 6 / 3 / 10 / 2 / 5 / 64 lanes, ragged row groups and
+    slabs, odd sizes."""
+    L = _lib.load()
+    assert L.msl_dwconv_fwd_eval_rows_ok(N, C, *dims, stride) == 1
+    assert L.msl_dwconv_fwd_eval_rows_ok(1, 2, 6, 64, 64, 2) == 0 and L.msl_dwconv_fwd_eval_rows_ok(1, 2, 6, 12, 6, 1) == 0
+    x, w = rnd(N, C, *dims, seed=4), rnd(C, 1, 3, 3, 3, seed=5, scale=0.4)
+    sc, sh = rnd(C, seed=6).abs() + 0.5, rnd(C, seed=7, scale=0.3)
+    a = affine_act(x, sc, sh) if affine else x
+    ref = F.conv3d(a, w, stride=stride, padding=1, groups=C)
+    y = torch.full(ref.shape, float("nan"), device=DEV)
+    _lib.call("msl_dwconv_fwd", ptr(K(x)), ptr(K(sc)) if affine else None, ptr(K(sh)) if affine else None,
+              ptr(K(w)), ptr(y), None, N, C, *dims, stride, 0, st())
+    close(y, ref, 1e-5, 1e-5, "dw fwd (eval rows)")
+    # the kernel a training forward of the same shape runs (with statistics) agrees to rounding
+    NP = L.msl_dwconv_fwd_num_partials(N, C, *dims, stride)
+    part = torch.zeros(2 * C * max(NP, 4096), dtype=torch.float64, device=DEV)
+    y2 = torch.full(ref.shape, float("nan"), device=DEV)
+    _lib.call("msl_dwconv_fwd", ptr(K(x)), ptr(K(sc)) if affine else None, ptr(K(sh)) if affine else None,
+              ptr(K(w)), ptr(y2), ptr(part), N, C, *dims, stride, 0, st())
+    close(y2, y, 1e-6, 1e-6, "eval rows vs the training-mode kernel")
+
+
 @pytest.mark.parametrize("N,C,dims,in_np,stride", [(2, 8, (16, 16, 16), 6, 1), (2, 8, (8, 8, 8), 100, 1),
                                                    (2, 32, (4, 4, 4), 70, 1), (1, 16, (5, 4, 4), 9, 1),
                                                    (2, 4, (6, 12, 16), 70, 1), (2, 16, (8, 8, 8), 70, 2),
