@@ -42,8 +42,12 @@ __global__ __launch_bounds__(256) void detect_prepare_kernel(const float* __rest
                                                              const float* __restrict__ scores,
                                                              const float* __restrict__ priors_c,
                                                              float* __restrict__ probs, float* __restrict__ boxes,
-                                                             int N, int P, int ncls) {
+                                                             int N, int P, int ncls, int* __restrict__ sel, int sel_count,
+                                                             int* __restrict__ ncand, int ncand_count) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  // the counters of the selection passes start at zero (was two memset launches in front of this kernel)
+  for (int j = i; j < sel_count; j += gridDim.x * 256) sel[j] = 0;
+  if (i < ncand_count) ncand[i] = 0;
   if (i >= N * P) return;
   const int n = i / P, p = i % P;
   const float* x = scores + (size_t)i * ncls;
@@ -392,11 +396,9 @@ int msl_detect_objects(const float* locs, const float* scores, const float* prio
   if (cap > 4096) return MSL_ERR_UNSUPPORTED;
   const int Wn = msl::cdiv(cap, 64), ncls1 = ncls - 1;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(ncand, 0, sizeof(int) * N * ncls1, st);
-  if (e != hipSuccess) return (int)e;
-  e = hipMemsetAsync(select_ws, 0, sizeof(int) * msl_detect_select_ws_ints(N, P, ncls), st);
-  if (e != hipSuccess) return (int)e;
-  hipLaunchKernelGGL(detect_prepare_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores, priors_c, probs, boxes, N, P, ncls);
+  if (msl_detect_select_ws_ints(N, P, ncls) >= (1ull << 31) || N * ncls1 > N * P) return MSL_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(detect_prepare_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores, priors_c, probs, boxes,
+                     N, P, ncls, select_ws, (int)msl_detect_select_ws_ints(N, P, ncls), ncand, N * ncls1);
   MSL_LAUNCH_CHECK();
   const dim3 gp(msl::cdiv(P, 256), N * ncls1);
   hipLaunchKernelGGL(detect_hist_kernel, gp, dim3(256), 0, st, probs, min_score, P, select_ws, ncand);
