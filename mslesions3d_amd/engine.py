@@ -403,8 +403,10 @@ class Engine:
                       bn.eps, ptr(vec[0]), ptr(vec[1]), C, st)
 
     # ------------------------------------------------------------------------------------------------
-    def forward(self, x, training, need_grad, want_features=False, nan_check=True):
-        """x (N,Cin,D,H,W) fp32 on the GPU -> (locs (N,P,6), scores (N,P,n_classes)) [+ dict of feature maps]."""
+    def forward(self, x, training, need_grad, want_features=False, nan_check=True, after_block=None):
+        """x (N,Cin,D,H,W) fp32 on the GPU -> (locs (N,P,6), scores (N,P,n_classes)) [+ dict of feature maps].
+        ``after_block``: {block index: callable} - side work (the trainer's target matching) to enqueue once that block's
+        launches have been issued."""
         if not x.is_cuda:
             raise _lib.HipKernelError("mslesions3d_amd runs on the HIP device only (no CPU fallback): move the "
                                       "model and the input to 'cuda'")
@@ -412,7 +414,7 @@ class Engine:
         m = self.model
         if getattr(m, "compute_dtype", "f32") == "bf16":
             return self._forward_bf16(x, training=training, need_grad=need_grad, want_features=want_features,
-                                      nan_check=nan_check)
+                                      nan_check=nan_check, after_block=after_block)
         x = x.contiguous().float()
         self.ensure_arena(x.device)
         pl = self.plan_for(x, need_grad)
@@ -497,6 +499,8 @@ class Engine:
                         ptr(blk.conv2.weight), ptr(pl.y[i]), ptr(pl.part_y[i]) if training else None, N, sp["cin"],
                         sp["cout"], S, st)
             flush()
+            if after_block and i in after_block:
+                after_block[i]()
             bn_done(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, f"stat_y{i}")
             if i in pl.fpad:
                 plain = None
@@ -645,7 +649,7 @@ class Engine:
         self.plans[key] = pl
         return pl
 
-    def _forward_bf16(self, x, training=False, need_grad=False, want_features=False, nan_check=True):
+    def _forward_bf16(self, x, training=False, need_grad=False, want_features=False, nan_check=True, after_block=None):
         """Forward with bf16 activations in HBM (csrc/bf16.hip + the bf16 head kernel): fp32 input volume, fp32 weights and
         BatchNorm vectors / statistics, bf16 everything in between, fp32 locs / scores out.  One stream (the head
         convolutions are issued in line)."""
@@ -708,6 +712,8 @@ class Engine:
                     self._bn_fwd(blk.bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], N * S, True, st)
                 self._k(f"pw_fwd{i}", "msl_pwconv_fwd_bf16", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
                         ptr(blk.conv2.weight), ptr(pl.y[i]), part(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
+            if after_block and i in after_block:
+                after_block[i]()
             if training and i in pl.feat_ids:  # the materialisation below reads the vectors
                 self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
             if i in pl.feat_ids and pl.f32_heads:

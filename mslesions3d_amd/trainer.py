@@ -35,6 +35,7 @@ class FusedTrainer:
         self.max_programs = 16
         self._staging = {}         # (image shape, target capacity) -> persistent input buffers (see _stage)
         self._stream = None        # the step runs on its own stream (graph capture needs a non-default one)
+        self.match_after = int(os.environ.get("MSL_MATCH_AFTER", "4"))  # block after which the target matching is enqueued
 
     def _reducer(self, arena):
         if self.reducer is None or self.reducer.arena is not arena:
@@ -57,16 +58,29 @@ class FusedTrainer:
         N, P, ncls = images.shape[0], m.priors_cxcycz.shape[0], m.n_classes
         st = lf._state(N, P, ncls, total_objects, dev)
         main = torch.cuda.current_stream().cuda_stream
+        after = None
         if eng.multi_stream:
-            # the matching only needs the ground truth: run it on the heads stream beside the forward pass
+            # the matching only needs the ground truth: it runs on a side stream beside the forward pass.  Not beside the
+            # stem / block 1 (bandwidth-bound kernels that a concurrent 37 k-prior arg-max slows down: the stem forward
+            # takes 49 us beside it, 38 alone) but beside the small launches from block `match_after` on, on the
+            # weight-gradient stream, which is idle during the forward pass (MSL_MATCH_AFTER=0: at the start, heads stream).
+            # A/B at 128^3 x 4 (tools/probes/r02_match_after.sh): after block 0 / 1 / 2 / 3 / 4 / 5 ->
+            # 0.870 / 0.869 / 0.863 / 0.861-0.866 / 0.858 / 0.861 ms (bf16 0.793 / - / 0.794 / 0.787 / 0.785 / -)
             pl0 = eng.plan_for(images, True)
-            sH = eng.side_streams(dev)[0].cuda_stream
-            eng._fork(pl0, "match_start", main, sH)
-            lf._run_match(st, N, gt_boxes, gt_labels, obj_off, total_objects, stream=sH)
-        locs, scores = eng.forward(images, training=True, need_grad=True, nan_check=False)
+            k = min(self.match_after, len(eng.layer_specs) - 1)  # (the hook of a block that does not exist would never fire)
+            sM = eng.side_streams(dev)[1 if k > 0 else 0].cuda_stream
+
+            def run_match():
+                eng._fork(pl0, "match_start", main, sM)
+                lf._run_match(st, N, gt_boxes, gt_labels, obj_off, total_objects, stream=sM)
+            if k > 0:
+                after = {k: run_match}
+            else:
+                run_match()
+        locs, scores = eng.forward(images, training=True, need_grad=True, nan_check=False, after_block=after)
         pl = eng.plan_for(images, True)
         if eng.multi_stream:
-            eng._fork(pl, "match_done", sH, main)
+            eng._fork(pl, "match_done", sM, main)
         if "upstream_alpha" not in st or st["upstream_alpha_value"] != float(lf.alpha):
             st["upstream_alpha"] = torch.tensor([1.0, float(lf.alpha)], dtype=torch.float32, device=dev)  # loss = conf + alpha*loc
             st["upstream_alpha_value"] = float(lf.alpha)
