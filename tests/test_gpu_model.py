@@ -566,6 +566,56 @@ def test_engine_schedule_options_agree():
         assert float((p - ref[1]).abs().max() / ref[1].abs().max()) < 1e-4, what
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_launch_placement_options_are_bit_identical(dtype):
+    """Where side work is enqueued (target matching after block 0 / 2 / 4 / past the last block), whether the tail blocks'
+    pointwise weight gradients and the head gradient images share a launch: pure scheduling - three optimisation steps end at
+    bit-identical parameters and losses."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (64, 64, 64), 2
+    x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, n, size)
+    boxes, labels = [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels]
+    ref = None
+    for match_after, batch_pw, batch_gp in [(4, True, True), (0, True, True), (2, False, True), (99, True, False), (4, False, False)]:
+        m = hip_model(1, size, lr=1e-3, batch_size=n).train()
+        m.compute_dtype = dtype
+        m._engine.batch_tail_pw, m._engine.batch_head_gpack = batch_pw, batch_gp
+        tr = FusedTrainer(m)
+        tr.match_after = match_after
+        losses = [tr.step(x, boxes, labels)["loss"] for _ in range(3)]
+        p = torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu()
+        if ref is None:
+            ref = (losses, p)
+        what = f"match_after={match_after} batch_tail_pw={batch_pw} batch_head_gpack={batch_gp}"
+        assert losses == ref[0], what
+        assert torch.equal(p, ref[1]), what
+
+
+def test_predict_input_buffer_skips_the_staging_copy():
+    """predict_step handed its own staging buffer (LSSD3D.predict_input_buffer) returns what it returns for a separate tensor."""
+    size, n = (64, 64, 64), 2
+    m = hip_model(1, size, batch_size=n).eval()
+    x = detinit.make_volume_batch(7, n, 1, size).to(DEV)
+    assert m.predict_input_buffer(x.shape) is None
+    a = m.predict_step({"img": x})
+    b = m.predict_step({"img": x})          # replayed program, staged copy
+    buf = m.predict_input_buffer(x.shape)
+    assert buf is not None and buf.data_ptr() != x.data_ptr() and torch.equal(buf, x)
+    x2 = detinit.make_volume_batch(8, n, 1, size).to(DEV)
+    ref2 = m.predict_step({"img": x2})
+    buf.copy_(x)
+    c = m.predict_step({"img": buf})        # no copy: the buffer itself
+    for u, v, w_ in zip(a, b, c):
+        for i in range(n):
+            assert torch.equal(u[i], v[i]) and torch.equal(u[i], w_[i])
+    buf.copy_(x2)
+    d = m.predict_step({"img": buf})
+    for u, v in zip(ref2, d):
+        for i in range(n):
+            assert torch.equal(u[i], v[i])
+
+
 def test_determinism_run_to_run():
     size, n = (64, 64, 64), 2
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
