@@ -123,7 +123,9 @@ def main():
     def run(nsteps):
         for s in range(nsteps):
             x, gb, gl, off, T = pool[s % len(pool)]
-            trainer.step_packed(x, gb, gl, off, T, sync=False, resident=True)
+            # the steps of a run are enqueued back to back on the trainer's stream (fence=False: no per-step round trip
+            # through the caller's stream); torch.cuda.synchronize() on both sides of the timed region orders everything else
+            trainer.step_packed(x, gb, gl, off, T, sync=False, resident=True, fence=os.environ.get("MSL_BENCH_FENCE", "0") == "1")
 
     run(args.warmup)
     torch.cuda.synchronize()

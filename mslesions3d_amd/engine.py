@@ -272,6 +272,8 @@ class Engine:
         # (dL/dlocs, dL/dscores) -> the zero-haloed head gradient images of ALL scales in one launch on the chain, in front of
         # the fork to the heads stream (was one ~6 us launch per scale, two of them on the heads stream)
         self.batch_head_gpack = os.environ.get("MSL_HEAD_GPACK_BATCH", "1") == "1"
+        # NaN-flag reset + head weight packing at the start of a forward pass on the heads stream instead of the chain
+        self.prologue_on_side = os.environ.get("MSL_PROLOGUE_ON_SIDE", "1") == "1"
         e = os.environ.get("MSL_WGRAD_ON_HEADS")
         self.wgrad_on_heads = None if e is None else {int(v) for v in e.split(",") if v.strip()}
         # default: fold only the BatchNorms with at most this many partials per channel (MSL_FOLD_NP_MAX).  Round 2 A/B at
@@ -426,8 +428,19 @@ class Engine:
         N = pl.N
         feats = m.base.features
         specs = self.layer_specs
-        _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
-        self._pack_head_weights(pl, st)  # MFMA-fragment copies of the head weights, all scales, once per pass
+        ev_pack = None
+        if self.multi_stream and self.prologue_on_side:
+            # the NaN-flag reset and the MFMA-fragment copies of the head weights are needed 200 us into the pass (first head
+            # convolution) and at its end (loss / NaN checks): on the heads stream they cost the dependency chain nothing
+            # (in front of the stem they were a memset + a launch + two dispatch gaps, ~20 us).  The heads stream first waits
+            # for everything the chain has done so far (the previous step's optimiser wrote the weights).
+            self._fork(pl, "fwd_start", st, stH)
+            _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, stH)
+            self._pack_head_weights(pl, stH)
+            ev_pack = self._record(pl, "head_pack_done", stH)
+        else:
+            _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
+            self._pack_head_weights(pl, st)  # MFMA-fragment copies of the head weights, all scales, once per pass
 
         fold_max = (1 << 30) if self.fold_bn else self.fold_np_max
         folds = lambda NP: training and NP <= fold_max  # is the BatchNorm with NP partials folded into its consumers?
@@ -520,6 +533,9 @@ class Engine:
                     ev = self._record(pl, f"fwd_feat{i}", st)
                     deferred.append(lambda ev=ev, i=i: (self._wait(stH, ev), self._head_forward(pl, i, stH)))
                 else:
+                    if ev_pack is not None:  # this scale's convolution runs on the chain: the packed weights come from stH
+                        self._wait(st, ev_pack)
+                        ev_pack = None
                     self._head_forward(pl, i, st)
         flush()
         if bn_layers:
@@ -664,13 +680,21 @@ class Engine:
         stH = self.side_streams(x.device)[0].cuda_stream if ms else st
         N = pl.N
         ncls = m.n_classes
-        _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
+        side_prologue = ms and self.prologue_on_side and pl.f32_heads  # as in the fp32 forward: off the dependency chain
+        ev_pack = None
+        if side_prologue:
+            self._fork(pl, "fwd_start", st, stH)
+            _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, stH)
+            self._pack_head_weights(pl, stH)
+            ev_pack = self._record(pl, "head_pack_done", stH)
+        else:
+            _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
         if not training:
             every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], 1, 1.0)]
             for i in range(1, len(specs)):
                 every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], 1, 1.0), (feats[i].bn2, pl.bn_y[i], pl.part_y[i], 1, 1.0)]
             self._finalize_all(pl, every, st, eval_mode=True)
-        if pl.f32_heads:  # MFMA-fragment copies of the head weights (forward and, in training, bwd-data)
+        if pl.f32_heads and not side_prologue:  # MFMA-fragment copies of the head weights (forward and, in training, bwd-data)
             self._pack_head_weights(pl, st)
         part = (lambda t: ptr(t)) if training else (lambda t: None)
         L = _lib.load()
@@ -725,6 +749,9 @@ class Engine:
                     self._fork(pl, f"fwd_feat{i}", st, stH)
                     self._head_forward(pl, i, stH)
                 else:
+                    if ev_pack is not None:  # the packed weights come from the heads stream
+                        self._wait(st, ev_pack)
+                        ev_pack = None
                     self._head_forward(pl, i, st)
             elif i in pl.feat_ids:
                 plain = None

@@ -22,6 +22,7 @@ class FusedAdam:
         self.exp_avg = None
         self.exp_avg_sq = None
         self.hp = None
+        self._hp_ring = None  # pinned staging slots of the hyper-parameter vector: [host tensor, event of its last copy]
 
     def _ensure(self):
         dev = next(self.model.parameters()).device
@@ -65,7 +66,19 @@ class FusedAdam:
         (the launch itself may then come from a recorded program)."""
         self._ensure()
         self.step_count += 1
-        self.hp.copy_(torch.tensor(self.hyper(grad_scale), dtype=torch.float32), non_blocking=True)
+        # Through a ring of PINNED staging buffers: a host-to-device copy from pageable memory holds the host until every
+        # earlier command of the stream - the whole previous step - has finished, so the next step's launches could only be
+        # enqueued into an idle GPU (~50 us per step).  A slot is reused only after the copy that last read it has run.
+        if self._hp_ring is None:
+            self._hp_ring = [[torch.empty(8, dtype=torch.float32).pin_memory(), None] for _ in range(8)]
+        slot = self._hp_ring[self.step_count % len(self._hp_ring)]
+        if slot[1] is None:
+            slot[1] = torch.cuda.Event()
+        else:
+            slot[1].synchronize()
+        slot[0].numpy()[:] = self.hyper(grad_scale)
+        self.hp.copy_(slot[0], non_blocking=True)
+        slot[1].record(torch.cuda.current_stream(self.hp.device))
 
     def state_dict(self):
         return {"step": self.step_count, "param_groups": [dict(g) for g in self.param_groups],

@@ -120,7 +120,7 @@ class FusedTrainer:
         off.copy_(obj_off, non_blocking=True)
         return x, gb, gl, off, cap
 
-    def step_packed(self, images, gt_boxes, gt_labels, obj_off, total_objects, sync=True, resident=False):
+    def step_packed(self, images, gt_boxes, gt_labels, obj_off, total_objects, sync=True, resident=False, fence=True):
         """One optimisation step on already packed targets (see MultiBoxLoss.pack_targets).  With ``sync=False``
         nothing is read back: the returned dict holds the device tensor ``loss_out`` = [conf, loc, n_positives].
 
@@ -128,7 +128,14 @@ class FusedTrainer:
         later steps replay that launch program (same kernels, same arguments, no Python in between).  By default the
         batch is first copied into persistent input buffers (``_stage``), so every step of a training loop replays one
         program; ``resident=True`` promises that the caller re-uses a small fixed set of input tensors (bench.py's
-        resident pool) and skips the copy: the programs are then keyed on those tensors (LRU-bounded)."""
+        resident pool) and skips the copy: the programs are then keyed on those tensors (LRU-bounded).
+
+        The step runs on the trainer's own stream.  With ``fence=True`` (default) that stream first waits for the caller's
+        current stream (inputs produced there) and the caller's stream afterwards waits for the step (results readable there):
+        two cross-queue hand-offs of ~16 us each per step, during which the GPU idles.  ``fence=False`` (with ``sync=False``
+        and ``resident=True``; replayed steps only) enqueues the step straight behind the previous one: consecutive steps are
+        ordered by the trainer's stream itself, and the CALLER must order anything else against it - ``trainer.fence()`` or
+        ``torch.cuda.synchronize()`` - before it reads parameters / ``loss_out`` or rewrites the resident inputs."""
         m = self.model
         if not images.is_cuda:
             raise _lib.HipKernelError("FusedTrainer runs on the HIP device only (no CPU fallback)")
@@ -141,7 +148,9 @@ class FusedTrainer:
             # high priority: the dependency chain must not queue behind the bulk weight-gradient work of the side streams
             self._stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MSL_MAIN_STREAM_PRIORITY", "-1")))
         caller = torch.cuda.current_stream(dev)
-        self._stream.wait_stream(caller)  # inputs produced on the caller's stream
+        unfenced = (not fence) and resident and not sync and self.use_programs  # decided for good once the program is known
+        if not unfenced:
+            self._stream.wait_stream(caller)  # inputs produced on the caller's stream
         # ssd3d.py:527-529: the reference steps the scheduler INSIDE training_step, which Lightning's automatic
         # optimisation runs inside the optimiser closure, i.e. before Adam applies the update: update k uses the
         # learning rate after k scheduler steps
@@ -158,6 +167,9 @@ class FusedTrainer:
             entry = self._programs.get(key) if self.use_programs else None
             if entry is not None:
                 self._programs.move_to_end(key)
+            elif unfenced:  # first step on these buffers: they may have just been written on the caller's stream
+                self._stream.wait_stream(caller)
+                unfenced = False
             if entry is None or eng.prof_all():
                 if self.use_programs:
                     _lib.start_recording()
@@ -175,7 +187,16 @@ class FusedTrainer:
                 prog, pl, st = entry["prog"], entry["plan"], entry["state"]
                 pl.generation += 1
                 pl.saved_input, pl.trained_mode = images, True
-                self.opt.prepare_step(grad_scale=1.0 / red.world)
+                if eng.multi_stream and eng.prologue_on_side:
+                    # the optimiser's hyper-parameter vector (this step's learning rate) is read by the last kernel of the
+                    # step: copy it on the heads stream, which the chain joins before the optimiser anyway, instead of in
+                    # front of the stem (the stream first waits for the previous step's optimiser, which still reads it)
+                    sH = eng.side_streams(dev)[0]
+                    sH.wait_stream(self._stream)
+                    with torch.cuda.stream(sH):
+                        self.opt.prepare_step(grad_scale=1.0 / red.world)
+                else:
+                    self.opt.prepare_step(grad_scale=1.0 / red.world)
                 if eng.prof is not None:
                     tags = frozenset(eng.prof_tags)
                     segs = entry.setdefault("native_timed", {}).get(tags)
@@ -186,7 +207,8 @@ class FusedTrainer:
                     if "native" not in entry:
                         entry["native"] = _lib.compile_program(prog, (), stream, dev.index or 0)
                     _lib.replay_native(entry["native"])
-        caller.wait_stream(self._stream)
+        if not unfenced:
+            caller.wait_stream(self._stream)
         self.last_plan = pl
         m.global_step += 1
         out = {"loss_out": st["loss_out"]}
@@ -197,6 +219,11 @@ class FusedTrainer:
                 raise Exception("Loss is NaN")
             out.update(conf=conf, loc=loc, loss=conf + float(m.loss_fn.alpha) * loc, n_positives=int(npos))
         return out
+
+    def fence(self):
+        """Order the caller's current stream behind every step enqueued so far (after ``step_packed(..., fence=False)``)."""
+        if self._stream is not None:
+            torch.cuda.current_stream(self._stream.device).wait_stream(self._stream)
 
     def step(self, images, boxes, labels, sync=True):
         gb, gl, off, T = MultiBoxLoss.pack_targets(boxes, labels, images.device)

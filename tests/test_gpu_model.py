@@ -592,6 +592,27 @@ def test_launch_placement_options_are_bit_identical(dtype):
         assert torch.equal(p, ref[1]), what
 
 
+def test_unfenced_replay_matches_the_fenced_steps():
+    """step_packed(..., sync=False, resident=True, fence=False): the replayed steps are enqueued straight behind each other on
+    the trainer's stream (no round trip through the caller's stream per step); after trainer.fence() the caller's stream sees
+    the same parameters and losses as after fenced steps, bit for bit."""
+    from mslesions3d_amd.ssd3d import MultiBoxLoss
+    from mslesions3d_amd.trainer import FusedTrainer
+    size, n = (64, 64, 64), 2
+    x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
+    boxes, labels = detinit.make_gt(8, n, size)
+    packed = MultiBoxLoss.pack_targets([b.to(DEV) for b in boxes], [t.to(DEV) for t in labels], torch.device(DEV))
+    out = []
+    for fence in (True, False):
+        m = hip_model(1, size, lr=1e-3, batch_size=n).train()
+        tr = FusedTrainer(m)
+        for _ in range(6):
+            r = tr.step_packed(x, *packed, sync=False, resident=True, fence=fence)
+        tr.fence()
+        out.append((torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu(), r["loss_out"].cpu()))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1])
+
+
 def test_predict_input_buffer_skips_the_staging_copy():
     """predict_step handed its own staging buffer (LSSD3D.predict_input_buffer) returns what it returns for a separate tensor."""
     size, n = (64, 64, 64), 2
