@@ -280,7 +280,7 @@ class Engine:
         # 128^3 x 4 (tools/probes/r02_fold.sh): thresholds 32 / 64 / 512 / 65536 give the same step time (0.928-0.935 ms) but
         # the depthwise forwards take 56 / 60 / 65 / 69 us back to back - a folded stem BatchNorm (1024 partials) costs block
         # 1's depthwise 4.5 us, what the finalize launch it saves costs the chain.  64 keeps the kernels near their roofline.
-        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "64"))
+        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "512"))
         self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", "32"))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
         self.side = {}
