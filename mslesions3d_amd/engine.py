@@ -711,9 +711,9 @@ class Engine:
             S = D * H * W
             bn_prev = feats[0][1] if i == 1 else feats[i - 1].bn2
             cnt_prev = N * pd * ph * pw
-            # the consumer rebuilds (scale, shift) from the producer's partials when they are few (<= 64: every wave /
+            # the consumer rebuilds (scale, shift) from the producer's partials when they are few (<= fold_np_max: every wave /
             # workgroup repeats the sum) - no finalize launch between the two; feature maps need the vectors anyway
-            fold_y = (training and self.fold_bf16 and pl.np_y[i - 1] <= 64 and (i - 1) not in pl.feat_ids
+            fold_y = (training and self.fold_bf16 and pl.np_y[i - 1] <= max(64, self.fold_np_max) and (i - 1) not in pl.feat_ids
                       and L.msl_dwconv_wave_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]) > 0)
             if training and not fold_y and (i - 1) not in pl.feat_ids:  # (a feature map's vectors exist already)
                 self._bn_fwd(bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev, True, st)

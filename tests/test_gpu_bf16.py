@@ -151,7 +151,7 @@ def test_materialize_and_head_fwd_bf16(N, C, dims):
     assert bool((locs[:, :off] == 7).all()) and bool((locs[:, off + 2 * S:] == 7).all())
 
 
-@pytest.mark.parametrize("NP", [1, 8, 64])
+@pytest.mark.parametrize("NP", [1, 8, 64, 256, 512])
 def test_bf16_bn_fold_is_bit_identical_to_the_explicit_finalize(NP):
     """The consumers that rebuild (scale, shift) from their producer's statistics partials (no finalize launch in between)
     must produce the bits of the explicit msl_bn_finalize + vector path."""
@@ -183,6 +183,10 @@ def test_bf16_bn_fold_is_bit_identical_to_the_explicit_finalize(NP):
         _lib.call("msl_dwconv_fwd_wave_bf16_fold", ptr(xb), ptr(part), NP, float(N * S), ptr(K(gamma)), ptr(K(beta)), 1e-5,
                   ptr(K(w)), ptr(yb), ptr(pb), N, C, *dims, stride, st())
         assert torch.equal(ya, yb) and torch.equal(pa, pb), f"depthwise stride {stride}"
+    if NP > 64:  # the pointwise consumer folds at most 64 partials (the engine sends longer lists through msl_bn_finalize)
+        assert L.msl_pwconv_fwd_bf16_fold(ptr(xb), ptr(part), NP, float(N * S), ptr(K(gamma)), ptr(K(beta)), 1e-5, None, None, None,
+                                          N, C, Cout, S, st()) != 0
+        return
     # pointwise
     w2 = rnd(Cout, C, seed=11) / C ** 0.5
     ya = torch.full((N, Cout, S), float("nan"), dtype=torch.bfloat16, device=DEV)
