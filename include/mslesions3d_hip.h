@@ -348,7 +348,8 @@ int msl_program_fn_id(const char* name);
 int msl_run_program(const int* fn_ids, const unsigned long long* slots, int stride, int n, int* failed_at);
 /* the same issued by two host threads: calls with lane[i] == 1 (the side streams' work) go to a persistent worker thread,
  * lane 0 (the dependency chain's stream) stays with the caller; wait_for[i] >= 0 names the msl_event_record entry that
- * must have been issued before the msl_stream_wait_event of entry i.  Every stream must belong to one lane. */
+ * must have been issued before the msl_stream_wait_event of entry i.  Every stream must belong to one lane.  Callers are
+ * serialised internally (one worker thread, one posted program at a time): safe from several host threads. */
 int msl_run_program_mt(const int* fn_ids, const unsigned long long* slots, int stride, int n, const int* lane,
                        const int* wait_for, int device, int* failed_at);
 /* asynchronous 32-bit fill (used to clear flags / counters inside a launch sequence) */

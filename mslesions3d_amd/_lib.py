@@ -261,6 +261,10 @@ def new_timed_event():
     return out.value
 
 
+def destroy_event(ev):
+    check(load().msl_event_destroy(ev), "msl_event_destroy")
+
+
 def elapsed_ms(e0, e1):
     out = ctypes.c_float()
     check(load().msl_event_elapsed_ms(e0, e1, ctypes.byref(out)), "msl_event_elapsed_ms")

@@ -37,6 +37,9 @@ __device__ __forceinline__ float iou6(const float* a, const float* b) {
   return inter / uni;
 }
 
+#define MSL_FN __device__ __forceinline__
+#include "softmax_exp.h"
+
 // probs (N, ncls-1, P): foreground class probabilities; boxes (N, P, 6) decoded corner boxes
 __global__ __launch_bounds__(256) void detect_prepare_kernel(const float* __restrict__ locs,
                                                              const float* __restrict__ scores,
@@ -51,11 +54,8 @@ __global__ __launch_bounds__(256) void detect_prepare_kernel(const float* __rest
   if (i >= N * P) return;
   const int n = i / P, p = i % P;
   const float* x = scores + (size_t)i * ncls;
-  float m = x[0];
-  for (int c = 1; c < ncls; ++c) m = fmaxf(m, x[c]);
-  float se = 0.f;
-  for (int c = 0; c < ncls; ++c) se += expf(x[c] - m);
-  for (int c = 1; c < ncls; ++c) probs[((size_t)n * (ncls - 1) + c - 1) * P + p] = expf(x[c] - m) / se;
+  // bit for bit what torch's CPU softmax yields (softmax_exp.h)
+  msl_softmax_foreground(x, ncls, probs + (size_t)n * (ncls - 1) * P + p, P);
   const float* g = locs + (size_t)i * 6;
   const float* pr = priors_c + (size_t)p * 6;
   float cxyz[3], sz[3];

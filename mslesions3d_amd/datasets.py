@@ -15,7 +15,9 @@ from os.path import join as pjoin
 import numpy as np
 import torch
 from scipy.ndimage import label as cc_label
-from torch.utils.data import DataLoader, Dataset
+import zlib
+
+from torch.utils.data import DataLoader, Dataset, Sampler
 
 from .synth import generate_volume, make_case  # noqa: F401
 
@@ -131,6 +133,38 @@ def _load(path_noext):
     return np.asarray(nib.load(path_noext + ".nii.gz").dataobj)
 
 
+class ShardSampler(Sampler):
+    """Data-parallel shard of one epoch (BASELINE north_star: "data-parallel training shards synthetic volumes across the
+    8 GPUs"): every rank draws the SAME permutation of the cases from (seed, epoch), pads it by wrapping around to a
+    multiple of the world size - every rank runs the same number of steps, each of which contains collectives - and takes
+    every world-th entry from its rank on.  Shards of one epoch are disjoint (up to the wrap-around padding) and cover the
+    data set; ``set_epoch`` re-deals them.  world = 1 is the plain seeded shuffle, so a resumed run (train.py --checkpoint)
+    sees the order the interrupted one would have seen."""
+
+    def __init__(self, n, rank=0, world=1, shuffle=True, seed=0):
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world {world}")
+        self.n, self.rank, self.world, self.shuffle, self.seed, self.epoch = n, rank, world, shuffle, seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def indices(self):
+        order = (np.random.RandomState((self.seed * 1000003 + self.epoch) % (2 ** 31 - 1)).permutation(self.n) if self.shuffle
+                 else np.arange(self.n))
+        if self.n == 0:
+            return order
+        per = -(-self.n // self.world)
+        order = np.resize(order, per * self.world)  # wrap-around padding
+        return order[self.rank::self.world]
+
+    def __iter__(self):
+        return iter(self.indices().tolist())
+
+    def __len__(self):
+        return -(-self.n // self.world) if self.n else 0
+
+
 class _Cases(Dataset):
     def __init__(self, root, subjects, n_classes, augmentations=None, seed=0):
         self.root, self.subjects, self.n_classes = root, subjects, n_classes
@@ -138,7 +172,16 @@ class _Cases(Dataset):
         for t in self.augmentations:
             if (t if isinstance(t, str) else t[0]) not in AUGMENTATIONS:
                 raise ValueError(f"unknown transform {t!r}")
-        self.rs = np.random.RandomState(seed)
+        # augmentation randomness is drawn per SAMPLE from (seed, epoch, subject): DataLoader workers are forked copies of
+        # this object, so a generator stored here would hand every worker - and every epoch - the same stream
+        self.seed, self.epoch = seed, 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def sample_rng(self, i):
+        key = f"{self.seed}:{self.epoch}:{self.subjects[i]}".encode()
+        return np.random.RandomState(zlib.crc32(key) & 0x7FFFFFFF)
 
     def __len__(self):
         return len(self.subjects)
@@ -152,9 +195,10 @@ class _Cases(Dataset):
             std = img[nz].std()
             img[nz] = (img[nz] - img[nz].mean()) / (std if std != 0 else 1.0)
         img, seg = img[None], np.asarray(seg)[None]  # add_channel
+        rs = self.sample_rng(i) if self.augmentations else None
         for t in self.augmentations:  # between normalizeintensity and bounding_boxes_generator (datasets.py:417-430)
             name, kw = (t, {}) if isinstance(t, str) else t
-            img, seg = AUGMENTATIONS[name](img, seg, self.rs, **kw)
+            img, seg = AUGMENTATIONS[name](img, seg, rs, **kw)
         img = np.ascontiguousarray(img)
         boxes, labels = boxes_from_segmentation(seg, self.n_classes)
         return {"img": torch.from_numpy(img), "boxes": boxes, "labels": labels, "seg": [boxes, labels], "subject": s,
@@ -177,7 +221,9 @@ class ExampleDataset:
 
     def __init__(self, n_classes=1, objects="multiple", percentage=1., augmentations=None, batch_size=8, num_workers=0,
                  verbose=False, random_state=970205, cache=False, subject=None,
-                 data_dir="../data/artificial_dataset", dataset_name=None):
+                 data_dir="../data/artificial_dataset", dataset_name=None, rank=0, world_size=1):
+        """``rank`` / ``world_size`` (not in the reference, which is single-GPU): this process's data-parallel shard of
+        the train and validation cases (``ShardSampler``)."""
         assert n_classes == 1 or n_classes == 2
         d = data_dir + "/multiple_objects" if objects == "multiple" else data_dir
         d = pjoin(d, "one_class") if n_classes == 1 else pjoin(d, "double_class")
@@ -185,6 +231,7 @@ class ExampleDataset:
         self.batch_size, self.num_workers, self.random_state = batch_size, num_workers, random_state
         self.n_classes, self.subject, self.percentage = n_classes, subject, percentage
         self.augmentations = augmentations
+        self.rank, self.world_size, self.epoch = rank, world_size, 0
         subs = sorted(s.replace("sub-", "")[:4] for s in os.listdir(pjoin(self.data_dir, "images")) if "sub-" in s)
         self.subjects_list = subs[:int(percentage * len(subs))] if percentage > 0 else subs
         self.train_dataset = self.test_dataset = self.predict_dataset = None
@@ -199,15 +246,25 @@ class ExampleDataset:
         self.test_dataset = _Cases(self.data_dir, test, self.n_classes)
         self.predict_dataset = _Cases(self.data_dir, train if stage == "predict_train" else test, self.n_classes)
 
-    def _loader(self, ds, shuffle, bs=None):
-        return DataLoader(ds, batch_size=bs or self.batch_size, shuffle=shuffle, num_workers=self.num_workers,
-                          collate_fn=collate_fn, drop_last=False)
+    def set_epoch(self, epoch):
+        """Call before ``train_dataloader()`` of every epoch: re-deals the shards and the augmentation draws."""
+        self.epoch = int(epoch)
+        if self.train_dataset is not None:
+            self.train_dataset.set_epoch(epoch)
+
+    def _loader(self, ds, shuffle, bs=None, shard=False):
+        sampler = None
+        if shard:
+            sampler = ShardSampler(len(ds), self.rank, self.world_size, shuffle, self.random_state)
+            sampler.set_epoch(self.epoch)
+        return DataLoader(ds, batch_size=bs or self.batch_size, shuffle=shuffle if sampler is None else False, sampler=sampler,
+                          num_workers=self.num_workers, collate_fn=collate_fn, drop_last=False)
 
     def train_dataloader(self):
-        return self._loader(self.train_dataset, True)
+        return self._loader(self.train_dataset, True, shard=True)
 
     def test_dataloader(self):
-        return self._loader(self.test_dataset, False)
+        return self._loader(self.test_dataset, False, shard=self.world_size > 1)
 
     def predict_dataloader(self):
         return self._loader(self.predict_dataset, False, 1)

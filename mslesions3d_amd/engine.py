@@ -374,6 +374,10 @@ class Engine:
         out = {}
         for t, evs in (self.prof or {}).items():
             out[t] = [(_lib.elapsed_ms(e[1], e[2]) if e[0] == "c" else e[0].elapsed_time(e[1])) for e in evs]
+            for e in evs:  # the native replay creates a fresh timed pair per tagged launch and replay: release them
+                if e[0] == "c":
+                    _lib.destroy_event(e[1])
+                    _lib.destroy_event(e[2])
         self.prof = None
         return out
 
@@ -802,7 +806,7 @@ class Engine:
         """Backward of the bf16 training step: activation gradients are bf16 tensors, weight gradients fp32 partial sums
         folded by the batched reduction.  Same three-stream schedule as the fp32 step (dependency chain on the main stream,
         head gradients of the earlier scales on the heads stream, weight gradients alternating over the two side streams);
-        a data-parallel reducer gets all its buckets at the end."""
+        a data-parallel reducer gets each bucket as soon as the launches producing it are enqueued (as in the fp32 step)."""
         m, specs, feats = self.model, self.layer_specs, self.model.base.features
         gv = self.arena.grad_views
         st = self._stream()
@@ -819,6 +823,9 @@ class Engine:
         pre_np = None
         if last not in pl.feat_ids:
             raise RuntimeError("the last backbone feature must feed a head")
+        wanted = getattr(on_bucket_ready, "stages", None)
+        groups = self._bucket_groups(on_bucket_ready) if wanted else {}
+        report = self._reporter(pl, on_bucket_ready, groups, st, stH, stW, stW, ms)
 
         def head(f, s_data, s_weight, done=None):
             C = specs[f]["cout"]
@@ -844,6 +851,7 @@ class Engine:
         head(last, st, stW)  # its data gradient starts the chain
         for f in reversed(side_feats) if ms else [f for f in pl.feat_ids if f != last]:
             head(f, stH, stH, done=f"head_done{f}" if ms else None)
+        report("heads", join_heads=True)
         for i in range(last, 0, -1):
             sp = specs[i]
             D, H, W = pl.dims[i]
@@ -886,6 +894,7 @@ class Engine:
             if not fused_stem:  # (its partials came with the fused pass: pl.partials_wf)
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
                         ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, sX)
+            report(i, join_heads=True)  # (odd blocks put their weight gradients on the heads stream)
         # stem: BatchNorm-backward sums, then the weight gradient with the BatchNorm backward applied on load
         od, oh, ow = pl.dims[0]
         S0 = od * oh * ow
@@ -908,12 +917,9 @@ class Engine:
         if ms:  # every gradient is complete once the side streams have been joined
             self._fork(pl, "bwd_join_w", stW, st)
             self._fork(pl, "bwd_join_h", stH, st)
-        self._grad_reduce(pl, "all", None, st)
-        if on_bucket_ready is not None:
-            for stage in ["heads"] + list(range(last, -1, -1)):
-                wanted = getattr(on_bucket_ready, "stages", None)
-                if wanted is None or stage in wanted:
-                    self._hook(on_bucket_ready, stage)
+        if not groups:  # single process: ONE reduction launch for every layer's partial sums, in front of the optimiser
+            self._grad_reduce(pl, "all", None, st)
+        report(0)
 
     def _finalize_all(self, pl, bn_layers, st, eval_mode=False):
         """One launch for the running statistics and backward vectors of the listed BatchNorms (table built once per
@@ -974,8 +980,10 @@ class Engine:
                             (ctypes.c_int * n)(*[self.layer_specs[f]["cout"] for f in pl.feat_ids]))
             pl.pack_key = key
         a = pl.pack_args  # host arrays: kept alive by the plan (a recorded launch program points at them)
-        self._k("head_pack", "msl_head_pack_weights_batch", ctypes.addressof(a[0]), ctypes.addressof(a[1]), ctypes.addressof(a[2]),
-                ctypes.addressof(a[3]), ctypes.addressof(a[4]), len(pl.feat_ids), m.n_classes, st)
+        n = len(pl.feat_ids)
+        for g0 in range(0, n, 4):  # the batch entry holds four scales (`--prediction_layers "1 2 3 5 7"`: two launches)
+            self._k("head_pack", "msl_head_pack_weights_batch", *[ctypes.addressof(a[c]) + 8 * g0 for c in range(4)],
+                    ctypes.addressof(a[4]) + 4 * g0, min(4, n - g0), m.n_classes, st)
 
     def _head_forward(self, pl, f, st):
         m = self.model
@@ -1036,8 +1044,10 @@ class Engine:
                 I(*[pl.dims[f][a] for f in pl.feat_ids]) for a in range(3)) + (I(*[pl.prior_off[f] for f in pl.feat_ids]),)
             pl.gpack_key = key
         a = pl.gpack_args  # host arrays: kept alive by the plan (a recorded launch program points at them)
-        self._k("head_gpack_all", "msl_head_grad_pack_batch", ptr(dlocs), ptr(dscores), *[ctypes.addressof(x) for x in a],
-                len(pl.feat_ids), pl.N, pl.P, self.model.n_classes, st)
+        n = len(pl.feat_ids)
+        for g0 in range(0, n, 4):  # four scales per launch (msl_head_grad_pack_batch)
+            self._k("head_gpack_all", "msl_head_grad_pack_batch", ptr(dlocs), ptr(dscores), ctypes.addressof(a[0]) + 8 * g0,
+                    *[ctypes.addressof(x) + 4 * g0 for x in a[1:]], min(4, n - g0), pl.N, pl.P, self.model.n_classes, st)
 
     def _head_backward(self, pl, f, dlocs, dscores, st, data_done_event=None, data=True, weight=True, packed=False):
         m, gv, ncls = self.model, self.arena.grad_views, self.model.n_classes
@@ -1057,6 +1067,60 @@ class Engine:
         # weight and bias slabs stay in head_ws[f] (folded by the batched gradient reduction)
         self._k(f"head_bww{f}", "msl_head_conv_bwd_weight", ptr(pl.dO[f]), ptr(pl.fpad[f]), None, None, None, None,
                 ptr(pl.head_ws[f]), pl.N, C, D, H, W, ncls, st)
+
+    def _reporter(self, pl, on_bucket_ready, groups, st, stH, stW, stX, ms):
+        """-> report(stage, join_heads=False): tell the data-parallel reducer that every launch producing the gradients of
+        ``stage`` ('heads', 7, ..., 0) has been enqueued - after making the stream the exchange will run on wait for the
+        streams that produced them and folding the stage's partial sums there."""
+        wanted = getattr(on_bucket_ready, "stages", None)
+
+        def report(stage, join_heads=False):
+            if on_bucket_ready is None or (wanted is not None and stage not in wanted):
+                return
+            comm = getattr(on_bucket_ready, "comm_stream", None)
+            if comm is not None and stage == 0 and getattr(on_bucket_ready, "final_on_main", False):
+                # every stream has just been joined into the chain: the last bucket is exchanged right here.  Collectives
+                # of one communicator must not overlap each other, so the chain first waits for the communication stream
+                # (whose buckets were issued ~0.3 ms ago: the wait is normally satisfied on arrival)
+                self._fork(pl, "bucket_tail", comm.cuda_stream, st)
+            elif comm is not None:
+                # the exchange has a stream of its own: IT waits for the streams that produced the bucket, the
+                # dependency chain never does (joining the weight-gradient stream into the chain three times per step
+                # cost 0.19 ms of a 1.0 ms step: tools/probes/dp_host_cost.py)
+                dst = comm.cuda_stream
+                self._fork(pl, f"bucket_m{stage}", st, dst)
+                if ms:
+                    if dst != stW:
+                        self._fork(pl, f"bucket_w{stage}", stW, dst)
+                    if join_heads and dst != stH:
+                        self._fork(pl, f"bucket_h{stage}", stH, dst)
+                    if stX != stW and dst != stX:
+                        self._fork(pl, f"bucket_x{stage}", stX, dst)
+            elif ms:  # the exchange follows the main stream: bring the side streams' work in first
+                self._fork(pl, f"bucket_w{stage}", stW, st)
+                if join_heads:
+                    self._fork(pl, f"bucket_h{stage}", stH, st)
+                if stX != stW:
+                    self._fork(pl, f"bucket_x{stage}", stX, st)
+            if stage in groups:  # fold the partial sums of this stage's buckets where their exchange will run
+                comm2 = getattr(on_bucket_ready, "comm_stream", None)
+                on_main = comm2 is None or (stage == 0 and getattr(on_bucket_ready, "final_on_main", False))
+                self._grad_reduce(pl, stage, groups[stage], st if on_main else comm2.cuda_stream)
+            # the waits above are part of the launch program; the reducer must not repeat them at the torch level - told per
+            # call (eager and replayed alike), never through state that outlives the call (ADVICE round 2: a flag left set
+            # by an fp32 step made a later bf16 step on the same reducer skip its wait)
+            presync = comm is not None and hasattr(on_bucket_ready, "presynced")
+
+            def fire(tag, presync=presync):
+                if presync:
+                    on_bucket_ready.presynced = True
+                try:
+                    on_bucket_ready(tag)
+                finally:
+                    if presync:
+                        on_bucket_ready.presynced = False
+            self._hook(fire, stage)
+        return report
 
     def backward(self, pl, dlocs, dscores, on_bucket_ready=None):
         """Given dL/dlocs, dL/dscores, fill the flat gradient arena.  ``on_bucket_ready(stage)`` is called right
@@ -1086,41 +1150,7 @@ class Engine:
         # (stage -> parameter names); single process: one reduction at the very end
         groups = self._bucket_groups(on_bucket_ready) if wanted else {}
 
-        def report(stage, join_heads=False):
-            if on_bucket_ready is None or (wanted is not None and stage not in wanted):
-                return
-            comm = getattr(on_bucket_ready, "comm_stream", None)
-            if comm is not None and stage == 0 and getattr(on_bucket_ready, "final_on_main", False):
-                # every stream has just been joined into the chain: the last bucket is exchanged right here.  Collectives
-                # of one communicator must not overlap each other, so the chain first waits for the communication stream
-                # (whose buckets were issued ~0.3 ms ago: the wait is normally satisfied on arrival)
-                self._fork(pl, "bucket_tail", comm.cuda_stream, st)
-                on_bucket_ready.presynced = True
-            elif comm is not None:
-                # the exchange has a stream of its own: IT waits for the streams that produced the bucket, the
-                # dependency chain never does (joining the weight-gradient stream into the chain three times per step
-                # cost 0.19 ms of a 1.0 ms step: tools/probes/dp_host_cost.py)
-                dst = comm.cuda_stream
-                self._fork(pl, f"bucket_m{stage}", st, dst)
-                if ms:
-                    if dst != stW:
-                        self._fork(pl, f"bucket_w{stage}", stW, dst)
-                    if join_heads and dst != stH:
-                        self._fork(pl, f"bucket_h{stage}", stH, dst)
-                    if stX != stW and dst != stX:
-                        self._fork(pl, f"bucket_x{stage}", stX, dst)
-                on_bucket_ready.presynced = True
-            elif ms:  # the exchange follows the main stream: bring the side streams' work in first
-                self._fork(pl, f"bucket_w{stage}", stW, st)
-                if join_heads:
-                    self._fork(pl, f"bucket_h{stage}", stH, st)
-                if stX != stW:
-                    self._fork(pl, f"bucket_x{stage}", stX, st)
-            if stage in groups:  # fold the partial sums of this stage's buckets where their exchange will run
-                comm2 = getattr(on_bucket_ready, "comm_stream", None)
-                on_main = comm2 is None or (stage == 0 and getattr(on_bucket_ready, "final_on_main", False))
-                self._grad_reduce(pl, stage, groups[stage], st if on_main else comm2.cuda_stream)
-            self._hook(on_bucket_ready, stage)
+        report = self._reporter(pl, on_bucket_ready, groups, st, stH, stW, stX, ms)
 
         # heads: the last scale feeds the chain immediately (main stream); the earlier scales are only needed when
         # the chain reaches their feature map, so they run on the heads stream beside blocks 7..4

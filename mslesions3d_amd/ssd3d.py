@@ -10,6 +10,7 @@ reference's scripts use (``training_step`` / ``validation_step`` / ``predict_ste
 ``load_from_checkpoint`` / ``log``), and ``mslesions3d_amd.trainer`` provides the minimal loop.
 """
 import math
+import os
 import warnings
 
 import numpy as np
@@ -604,7 +605,7 @@ class LSSD3D(nn.Module):
             return v.tolist()
         return v
 
-    def save_checkpoint(self, path, optimizer=None, scheduler=None):
+    def save_checkpoint(self, path, optimizer=None, scheduler=None, loop_state=None):
         """Lightning's key layout (``state_dict`` / ``hyper_parameters`` / ``epoch`` / ``global_step`` /
         ``optimizer_states`` / ``lr_schedulers``, reference train.py:171-176,185) with tensors and plain types only.
         ``optimizer`` may be a FusedAdam or a FusedTrainer (then its scheduler is saved too)."""
@@ -618,7 +619,11 @@ class LSSD3D(nn.Module):
             ckpt["optimizer_states"] = [self._plain(optimizer.state_dict())]
         if scheduler is not None:
             ckpt["lr_schedulers"] = [self._plain(scheduler.state_dict())]
-        torch.save(ckpt, path)
+        if loop_state is not None:  # train.py's own bookkeeping (top-3 list, early-stopping counter): plain types
+            ckpt["loop_state"] = self._plain(loop_state)
+        tmp = f"{path}.tmp{os.getpid()}"
+        torch.save(ckpt, tmp)
+        os.replace(tmp, path)  # a reader (or a crash) never sees a half-written checkpoint
 
     @staticmethod
     def read_checkpoint(path, map_location="cpu"):

@@ -88,8 +88,11 @@ class OracleSSD3D(nn.Module):
     backbone (ssd3d.py:238,270,293 -> :102-110), consuming RNG and touching BN running stats."""
 
     def __init__(self, n_classes=2, input_channels=1, input_size=(64, 64, 64), min_object_size=6,
-                 max_object_size=14, emulate_reference_init=True):
+                 max_object_size=14, emulate_reference_init=True, feature_ids=FEATURE_IDS):
+        """``feature_ids``: the keys of the reference's ``aspect_ratios`` argument (ssd3d.py:204-205; train.py:131
+        ``--prediction_layers``), default 3 5 7."""
         super().__init__()
+        self.feature_ids = FEATURE_IDS = tuple(feature_ids)
         self.n_classes = n_classes
         self.input_size = tuple(input_size)
         self.input_channels = input_channels
@@ -113,7 +116,7 @@ class OracleSSD3D(nn.Module):
             x = layer(x)
 
     def forward(self, image):
-        locs, scores = self.pred_convs(self.base(image))
+        locs, scores = self.pred_convs(self.base(image, keep=self.feature_ids))
         if torch.isnan(scores).any() or torch.isnan(locs).any():  # ssd3d.py:258-261
             raise Exception("NaN in SSD forward")
         return locs, scores

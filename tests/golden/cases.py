@@ -6,6 +6,7 @@ import torch
 from . import detinit
 
 SIZE_C64 = (64, 64, 64)
+FIVE_SCALES = (1, 2, 3, 5, 7)  # `--prediction_layers "1 2 3 5 7"`
 P_C64 = 1168
 
 
@@ -63,6 +64,33 @@ def detect_inputs(case, p=P_C64):
         scores[..., 0] = 0.0
         scores[..., 1] = torch.round(scores[..., 1] * 2) / 2
         locs = torch.round(locs * 4) / 4
+    return locs, scores
+
+
+def multiclass_gt(seed, n, size, n_fg=2):
+    """Ground truth with foreground labels 1..n_fg (deterministic, alternating from a per-image offset): the
+    3-class fixtures (ssd3d.py:132 head width, :384 class loop)."""
+    boxes, labels = detinit.make_gt(seed, n, size, n_obj_range=(2, 5))
+    labels = [1 + (torch.arange(len(l)) + i) % n_fg for i, l in enumerate(labels)]
+    return boxes, [l.to(torch.long) for l in labels]
+
+
+def multiclass_detect_cases():
+    """3-class detect_objects settings: the class loop (ssd3d.py:384), and with total > top_k the cross-class
+    re-sort (ssd3d.py:449-453)."""
+    return {
+        "mc_ms03_k10": dict(head_seed=71, n=2, min_score=0.3, max_overlap=0.5, top_k=10),    # re-sort across classes
+        "mc_ms04_k100": dict(head_seed=72, n=2, min_score=0.4, max_overlap=0.45, top_k=100),  # no truncation
+        "mc_ms02_k25": dict(head_seed=73, n=1, min_score=0.2, max_overlap=0.3, top_k=25),
+        "mc_one_class_empty": dict(head_seed=74, n=2, min_score=0.5, max_overlap=0.5, top_k=20, kill_class=1),
+    }
+
+
+def multiclass_detect_inputs(case, p=P_C64, n_classes=3):
+    locs, scores = detinit.make_head_outputs(case["head_seed"], case["n"], p, n_classes=n_classes, loc_std=0.6, score_std=2.5)
+    if "kill_class" in case:  # no candidate of that class anywhere: the class loop skips it (ssd3d.py:391-392)
+        scores = scores.clone()
+        scores[..., case["kill_class"]] = -30.0
     return locs, scores
 
 

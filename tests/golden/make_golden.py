@@ -249,6 +249,136 @@ def gen_map(ref_utils):
     save("map.npz", **out)
 
 
+def gen_multiclass(ref):
+    """n_classes = 3 (background + two lesion classes): head width (ssd3d.py:132), label gather and per-class confidence loss
+    (ssd3d.py:871-933), the class loop of detect_objects (ssd3d.py:384) and its cross-class top-k re-sort (:449-453)."""
+    size, n = cases.SIZE_C64, 2
+    m = build_ref_model(ref, n_classes=3, input_size=size)
+    x = detinit.make_volume_batch(5, n, 1, size)
+    boxes, labels = cases.multiclass_gt(8, n, size)
+    out = {"gt_labels_0": labels[0].numpy(), "gt_labels_1": labels[1].numpy()}
+    m.eval()
+    with torch.no_grad():
+        le, se = m(x)
+        out["eval_locs"], out["eval_scores"] = le.numpy(), se.numpy()
+        b, l, s = m.detect_objects(le, se, 0.34, 0.5, 20)  # the untrained net's softmax sits near 1/3
+        for i in range(n):
+            out[f"e2e__boxes_{i}"], out[f"e2e__labels_{i}"], out[f"e2e__scores_{i}"] = b[i].numpy(), l[i].numpy(), s[i].numpy()
+    m.train()
+    locs, scores = m(x)
+    (conf, loc), g = capture_loss_locals(m.loss_fn, locs, scores, boxes, labels)
+    (conf + m.loss_fn.alpha * loc).backward()
+    out["train_locs"], out["train_scores"] = locs.detach().numpy(), scores.detach().numpy()
+    out["true_classes"] = g["true_classes"].numpy().astype(np.int8)
+    out["true_locs"] = g["true_locs"].numpy()
+    out["conf"], out["loc"] = np.float32(conf.item()), np.float32(loc.item())
+    names, gnorm, ghead = [], [], []
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        names.append(k)
+        gnorm.append(p.grad.double().norm().item())
+        ghead.append(np.resize(p.grad.reshape(-1)[:4].numpy(), 4))
+    out["grad_names"], out["grad_norm"], out["grad_head4"] = np.array(names), np.array(gnorm), np.stack(ghead)
+    # loss on fixed head outputs (dL/dlocs, dL/dscores of the reference's autograd)
+    hl, hs = detinit.make_head_outputs(81, n, cases.P_C64, n_classes=3)
+    hl.requires_grad_(True)
+    hs.requires_grad_(True)
+    (c2, l2), g2 = capture_loss_locals(ref.MultiBoxLoss(m.priors_cxcycz, threshold=[0.1, 0.2], alpha=1.0), hl, hs, boxes, labels)
+    (c2 + l2).backward()
+    out["heads__conf"], out["heads__loc"] = np.float32(c2.item()), np.float32(l2.item())
+    out["heads__true_classes"] = g2["true_classes"].numpy().astype(np.int8)
+    out["heads__dlocs_nz"] = hl.grad.numpy()[g2["true_classes"].numpy() > 0]
+    out["heads__dscores"] = hs.grad.numpy()
+    for name, c in cases.multiclass_detect_cases().items():
+        dl, ds = cases.multiclass_detect_inputs(c)
+        with torch.no_grad():
+            b, l, s = m.detect_objects(dl, ds, c["min_score"], c["max_overlap"], c["top_k"])
+        for i in range(c["n"]):
+            out[f"{name}__boxes_{i}"], out[f"{name}__labels_{i}"], out[f"{name}__scores_{i}"] = b[i].numpy(), l[i].numpy(), s[i].numpy()
+    save("multiclass.npz", **out)
+
+
+def gen_fivescale(ref):
+    """`--prediction_layers "1 2 3 5 7"` (train.py:131 -> aspect_ratios keys, ssd3d.py:204): five prediction scales."""
+    size, n = cases.SIZE_C64, 2
+    ar = {l: [1.] for l in cases.FIVE_SCALES}
+    m = build_ref_model(ref, input_size=size, aspect_ratios=ar)
+    x = detinit.make_volume_batch(5, n, 1, size)
+    boxes, labels = detinit.make_gt(8, n, size)
+    out = {"priors_n": np.int64(m.priors_cxcycz.shape[0]),
+           "priors_sha256": np.frombuffer(hashlib.sha256(m.priors_cxcycz.contiguous().numpy().tobytes()).digest(), dtype=np.uint8),
+           "scales": np.array([m.scales[k] for k in cases.FIVE_SCALES], dtype=np.float64),
+           "sd_keys": np.array(list(m.state_dict().keys()))}
+    m.eval()
+    with torch.no_grad():
+        le, se = m(x)
+        out["eval_locs"], out["eval_scores"] = le.numpy().reshape(-1)[::7], se.numpy().reshape(-1)[::7]
+        b, l, s = m.detect_objects(le, se, 0.5, 0.5, 30)
+        for i in range(n):
+            out[f"e2e__labels_{i}"], out[f"e2e__scores_{i}"] = l[i].numpy(), s[i].numpy()
+    m.train()
+    locs, scores = m(x)
+    conf, loc = m.loss_fn(locs, scores, boxes, labels)
+    (conf + m.loss_fn.alpha * loc).backward()
+    out["train_locs"], out["train_scores"] = locs.detach().numpy().reshape(-1)[::7], scores.detach().numpy().reshape(-1)[::7]
+    out["conf"], out["loc"] = np.float32(conf.item()), np.float32(loc.item())
+    names, gnorm = [], []
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            names.append(k)
+            gnorm.append(p.grad.double().norm().item())
+    out["grad_names"], out["grad_norm"] = np.array(names), np.array(gnorm)
+    save("fivescale.npz", **out)
+
+
+def gen_signatures(ref_ssd3d, ref_mobilenet, ref_utils):
+    """The drop-in boundary as data: names, parameter order, kinds and defaults of every public class /
+    function on the path, read off the reference's own objects with ``inspect.signature`` -> tests/golden/signatures.json."""
+    import inspect
+    import json
+    import base_network as ref_base  # on sys.path through _ref_loader
+
+    def sig(fn):
+        rows = []
+        for prm in inspect.signature(fn).parameters.values():
+            d = prm.default
+            if d is inspect.Parameter.empty:
+                d = "<required>"
+            elif not isinstance(d, (int, float, str, bool, type(None), list, dict, tuple)):
+                d = repr(d)
+            rows.append([prm.name, prm.kind.name, list(d) if isinstance(d, tuple) else d])
+        return rows
+
+    table = {}
+    classes = {"ssd3d": (ref_ssd3d, ["MobileNetBase", "PredictionConvolutions", "LSSD3D", "MultiBoxLoss"]),
+               "mobilenet": (ref_mobilenet, ["Block"]),
+               "base_network": (ref_base, ["ConvNetBase"])}
+    methods = {"MobileNetBase": ["__init__", "init", "forward", "get_feature_map_infos"],
+               "PredictionConvolutions": ["__init__", "init", "forward"],
+               "LSSD3D": ["__init__", "forward", "init", "create_prior_boxes", "detect_objects", "training_step", "validation_step",
+                          "predict_step", "configure_optimizers"],
+               "MultiBoxLoss": ["__init__", "forward"], "Block": ["__init__", "forward"],
+               "ConvNetBase": ["__init__", "init", "forward", "get_feature_map_infos"]}
+    for mod, (module, names) in classes.items():
+        for cname in names:
+            cls = getattr(module, cname)
+            for meth in methods[cname]:
+                table[f"{mod}.{cname}.{meth}"] = sig(getattr(cls, meth))
+    functions = {"mobilenet": (ref_mobilenet, ["conv_bn"]), "base_network": (ref_base, ["get_n_params"]),
+                 "utils": (ref_utils, ["cxcycz_to_xyz", "gcxgcygcz_to_cxcycz", "cxcycz_to_gcxgcygcz", "xyz_to_cxcycz", "find_intersection3d",
+                                       "find_jaccard_overlap3d", "volume", "compute_metrics_per_class", "calculate_mAP"])}
+    for mod, (module, names) in functions.items():
+        for fname in names:
+            table[f"{mod}.{fname}"] = sig(getattr(module, fname))
+    consts = {"mobilenet.MOBILENET_CONFIGS": ref_mobilenet.MOBILENET_CONFIGS, "base_network.CONVNET_CONFIGS": ref_base.CONVNET_CONFIGS,
+              "ssd3d.ASPECT_RATIOS": getattr(ref_ssd3d, "ASPECT_RATIOS", None)}
+    path = os.path.join(OUT, "signatures.json")
+    with open(path, "w") as f:
+        json.dump({"signatures": table, "constants": json.loads(json.dumps(consts, default=list))}, f, indent=1, sort_keys=True)
+    print("wrote signatures.json", len(table), "callables")
+
+
 def main():
     ref_ssd3d, ref_mobilenet, ref_utils = _ref_loader.load_reference()
     only = sys.argv[1:]
@@ -260,7 +390,9 @@ def main():
             # BASELINE configs[4]: multi-modal 2-channel (T1 + FLAIR) 128^3, batch 4
             ("network_a2_2ch128", lambda: gen_network(ref_ssd3d, "a2_2ch128", 4, 2, (128, 128, 128), 61)),
             ("network_noncube", lambda: gen_network(ref_ssd3d, "noncube", 2, 1, (48, 64, 64), 7)),
-            ("detect", lambda: gen_detect(ref_ssd3d)), ("map", lambda: gen_map(ref_utils))]
+            ("detect", lambda: gen_detect(ref_ssd3d)), ("map", lambda: gen_map(ref_utils)),
+            ("multiclass", lambda: gen_multiclass(ref_ssd3d)), ("fivescale", lambda: gen_fivescale(ref_ssd3d)),
+            ("signatures", lambda: gen_signatures(ref_ssd3d, ref_mobilenet, ref_utils))]
     for name, job in jobs:
         if not only or name in only:
             job()

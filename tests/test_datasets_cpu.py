@@ -161,3 +161,52 @@ def test_train_dataset_applies_the_selected_augmentations(tmp_path):
     assert changed > 0
     for i in range(len(plain.test_dataset)):  # the test pipeline is never augmented (datasets.py:417)
         assert torch.equal(plain.test_dataset[i]["img"], augd.test_dataset[i]["img"])
+
+
+# ---- data-parallel shards and per-sample augmentation draws --------------------------------------------------------------
+@pytest.mark.parametrize("n,world", [(8, 2), (13, 4), (5, 8), (16, 1)])
+def test_shard_sampler_deals_disjoint_covering_shards(n, world):
+    shards = []
+    for r in range(world):
+        s = DS.ShardSampler(n, r, world, shuffle=True, seed=970205)
+        s.set_epoch(3)
+        shards.append(list(s))
+        assert len(shards[-1]) == len(s) == -(-n // world)   # every rank runs the same number of steps
+    flat = [i for sh in shards for i in sh]
+    assert set(flat) == set(range(n))                          # the shards cover the data set
+    assert len(flat) - len(set(flat)) == (-n) % world          # duplicates only from the wrap-around padding
+    if n >= world:
+        for a in range(world):
+            for b in range(a + 1, world):
+                assert not (set(shards[a]) & set(shards[b])) or (-n) % world
+    again = DS.ShardSampler(n, 0, world, shuffle=True, seed=970205)
+    again.set_epoch(4)
+    if n > 2:
+        assert list(again) != shards[0] or n <= world          # another epoch, another deal
+    again.set_epoch(3)
+    assert list(again) == shards[0]                            # a resumed run sees the same order
+    with pytest.raises(ValueError):
+        DS.ShardSampler(4, 2, 2)
+
+
+def test_augmentation_draws_differ_across_workers_and_epochs(tmp_path):
+    """with num_workers > 0 every DataLoader worker is a forked copy of the data set, re-created each epoch -
+    a generator stored on the data set hands every worker and every epoch the same flips.  The draws are now a function of
+    (seed, epoch, subject): different per sample, different per epoch, identical for a re-run of the same epoch."""
+    DS.generate_artificial_dataset(str(tmp_path), "toy", num_images=10, image_size=(16, 16, 16), object_size=(3, 6))
+    aug = DS.select_augmentations(["flip", "rotate90"])
+    d = DS.ExampleDataset(n_classes=1, batch_size=1, num_workers=2, data_dir=str(tmp_path), dataset_name="toy", augmentations=aug)
+    d.setup("fit")
+
+    def epoch(e):
+        d.set_epoch(e)
+        return {b["subject"][0]: b["img"].clone() for b in d.train_dataloader()}
+    e0, e0b, e1 = epoch(0), epoch(0), epoch(1)
+    assert set(e0) == set(e1) == set(e0b) and len(e0) == 8
+    assert all(torch.equal(e0[s], e0b[s]) for s in e0)               # deterministic per (seed, epoch, subject)
+    assert sum(not torch.equal(e0[s], e1[s]) for s in e0) >= 3       # another epoch draws differently
+    # the draws of two samples of one epoch are independent streams (not one stream replayed per worker)
+    ds = d.train_dataset
+    ds.set_epoch(0)
+    firsts = {tuple(ds.sample_rng(i).randint(0, 1 << 30, 4)) for i in range(len(ds))}
+    assert len(firsts) == len(ds)

@@ -76,3 +76,31 @@ def test_checkpoint_with_pickled_object_is_refused(tmp_path):
     import inspect
     import mslesions3d_amd.ssd3d as S
     assert "weights_only=False" not in inspect.getsource(S)
+
+
+def test_softmax_restatement_is_bit_exact(tmp_path):
+    """csrc/softmax_exp.h (the text detect.hip compiles for the GPU) built for the host with g++ and compared with
+    ``torch.softmax`` bit for bit: the NMS candidate order hangs on the last bit of these probabilities (ssd3d.py:363,
+    :397), so the kernel restates ATen's CPU algorithm (Sleef expf, sum in class order, multiply by the reciprocal)."""
+    import ctypes
+    import subprocess
+    src = tmp_path / "sm.cpp"
+    hdr = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mslesions3d_amd", "csrc", "softmax_exp.h")
+    src.write_text('#define MSL_FN static inline\n#include "%s"\nextern "C" void run(const float* x, int n, int ncls, float* out) {\n'
+                   '  for (int i = 0; i < n; ++i) msl_softmax_foreground(x + (long)i * ncls, ncls, out + (long)i * (ncls - 1), 1);\n}\n' % hdr)
+    so = tmp_path / "sm.so"
+    subprocess.run(["g++", "-O2", "-std=c++20", "-ffp-contract=off", "-mfma", "-shared", "-fPIC", str(src), "-o", str(so)], check=True)
+    lib = ctypes.CDLL(str(so))
+    rs = np.random.RandomState(3)
+    for ncls, std in ((2, 2.5), (2, 12.0), (3, 2.5), (5, 1.0), (2, 60.0)):
+        x = (rs.randn(300000, ncls) * std).astype(np.float32)
+        out = np.empty((x.shape[0], ncls - 1), np.float32)
+        lib.run(x.ctypes.data_as(ctypes.c_void_p), x.shape[0], ncls, out.ctypes.data_as(ctypes.c_void_p))
+        ref = torch.softmax(torch.from_numpy(x), dim=1).numpy()[:, 1:]
+        assert np.array_equal(out.view(np.uint32), np.ascontiguousarray(ref).view(np.uint32)), (ncls, std)
+    # three-dimensional input as detect_objects sees it (N, P, ncls), softmax over dim 2
+    x = (rs.randn(2, 9344, 2) * 2.5).astype(np.float32)
+    out = np.empty((2 * 9344, 1), np.float32)
+    lib.run(x.ctypes.data_as(ctypes.c_void_p), 2 * 9344, 2, out.ctypes.data_as(ctypes.c_void_p))
+    ref = torch.softmax(torch.from_numpy(x), dim=2).numpy()[..., 1].reshape(-1, 1)
+    assert np.array_equal(out.view(np.uint32), np.ascontiguousarray(ref).view(np.uint32))

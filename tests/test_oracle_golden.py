@@ -209,3 +209,93 @@ def test_calculate_map(name, ov):
         np.testing.assert_allclose(float(d[k]), float(g[f"{tag}__{k}"]), rtol=1e-6, equal_nan=True)
     for k in ("TP", "FP", "found_boxes_volumes_per_class", "not_found_boxes_volumes_per_class"):
         np.testing.assert_allclose(np.asarray(d[k], np.float32), g[f"{tag}__{k}"], rtol=1e-6)
+
+
+def test_multiclass_three_classes():
+    """n_classes = 3 (tests/golden/multiclass.npz, minted from the reference): head width ssd3d.py:132, label gather and
+    confidence loss ssd3d.py:871-933, class loop ssd3d.py:384 and the cross-class top-k re-sort ssd3d.py:449-453."""
+    g = golden("multiclass")
+    size, n = cases.SIZE_C64, 2
+    m = oracle_model(1, size, n_classes=3)
+    x = detinit.make_volume_batch(5, n, 1, size)
+    boxes, labels = cases.multiclass_gt(8, n, size)
+    assert all(np.array_equal(l.numpy(), g[f"gt_labels_{i}"]) for i, l in enumerate(labels))
+    assert {int(v) for l in labels for v in l} == {1, 2}
+    m.eval()
+    with torch.no_grad():
+        le, se = m(x)
+    assert np.array_equal(le.numpy(), g["eval_locs"]) and np.array_equal(se.numpy(), g["eval_scores"])
+    b, l, s = OD.detect_objects(le, se, m.priors_cxcycz, 0.34, 0.5, 20)
+    for i in range(n):
+        assert np.array_equal(l[i].numpy(), g[f"e2e__labels_{i}"])
+        assert np.array_equal(b[i].numpy(), g[f"e2e__boxes_{i}"]) and np.array_equal(s[i].numpy(), g[f"e2e__scores_{i}"])
+    m.train()
+    locs, scores = m(x)
+    assert scores.shape == (n, cases.P_C64, 3)
+    assert np.array_equal(locs.detach().numpy(), g["train_locs"]) and np.array_equal(scores.detach().numpy(), g["train_scores"])
+    tc, tl, _ = OMB.match_batch(boxes, labels, m.priors_cxcycz, [0.1, 0.2])
+    assert np.array_equal(tc.numpy().astype(np.int8), g["true_classes"]) and np.array_equal(tl.numpy(), g["true_locs"])
+    assert set(np.unique(g["true_classes"])) == {-1, 0, 1, 2}
+    conf, loc = OMB.multibox_loss(locs, scores, boxes, labels, m.priors_cxcycz, [0.1, 0.2])
+    (conf + loc).backward()
+    assert abs(conf.item() - float(g["conf"])) <= 1e-6 * abs(float(g["conf"]))
+    assert abs(loc.item() - float(g["loc"])) <= 1e-6 * abs(float(g["loc"]))
+    grads = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert list(grads.keys()) == list(g["grad_names"])
+    for k, norm, head in zip(g["grad_names"], g["grad_norm"], g["grad_head4"]):
+        assert abs(grads[k].double().norm().item() - norm) <= 1e-5 * max(norm, 1e-6), k
+    hl, hs = detinit.make_head_outputs(81, n, cases.P_C64, n_classes=3)
+    hl.requires_grad_(True)
+    hs.requires_grad_(True)
+    c2, l2 = OMB.multibox_loss(hl, hs, boxes, labels, m.priors_cxcycz, [0.1, 0.2])
+    (c2 + l2).backward()
+    assert abs(c2.item() - float(g["heads__conf"])) <= 1e-6 * abs(float(g["heads__conf"]))
+    assert np.allclose(hs.grad.numpy(), g["heads__dscores"], rtol=1e-5, atol=1e-9)
+    assert np.allclose(hl.grad.numpy()[g["heads__true_classes"] > 0], g["heads__dlocs_nz"], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("name", list(cases.multiclass_detect_cases().keys()))
+def test_multiclass_detect(name):
+    g = golden("multiclass")
+    c = cases.multiclass_detect_cases()[name]
+    locs, scores = cases.multiclass_detect_inputs(c)
+    pri = oracle_model(1, cases.SIZE_C64, n_classes=3).priors_cxcycz
+    b, l, s = OD.detect_objects(locs, scores, pri, c["min_score"], c["max_overlap"], c["top_k"])
+    seen = set()
+    for i in range(c["n"]):
+        assert np.array_equal(l[i].numpy(), g[f"{name}__labels_{i}"])
+        assert np.array_equal(s[i].numpy(), g[f"{name}__scores_{i}"])
+        assert np.array_equal(b[i].numpy(), g[f"{name}__boxes_{i}"])
+        seen |= set(l[i].tolist())
+    assert seen == ({2} if "kill_class" in c else {1, 2})
+    if name == "mc_ms02_k25":  # the re-sort really interleaves the classes (not class 1 first, then class 2)
+        lab = g[f"{name}__labels_0"]
+        assert (np.diff(lab) != 0).sum() > 4 and np.all(np.diff(g[f"{name}__scores_0"]) <= 0)
+
+
+def test_five_prediction_scales():
+    """`--prediction_layers "1 2 3 5 7"`: the oracle with five scales against the reference-minted fivescale.npz."""
+    g = golden("fivescale")
+    size, n = cases.SIZE_C64, 2
+    m = oracle_model(1, size, feature_ids=cases.FIVE_SCALES)
+    assert list(m.state_dict().keys()) == list(g["sd_keys"])
+    p = m.priors_cxcycz.contiguous().numpy()
+    assert p.shape[0] == int(g["priors_n"]) and hashlib.sha256(p.tobytes()).digest() == bytes(g["priors_sha256"])
+    x = detinit.make_volume_batch(5, n, 1, size)
+    boxes, labels = detinit.make_gt(8, n, size)
+    m.eval()
+    with torch.no_grad():
+        le, se = m(x)
+    assert np.array_equal(le.numpy().reshape(-1)[::7], g["eval_locs"]) and np.array_equal(se.numpy().reshape(-1)[::7], g["eval_scores"])
+    b, l, s = OD.detect_objects(le, se, m.priors_cxcycz, 0.5, 0.5, 30)
+    for i in range(n):
+        assert np.array_equal(l[i].numpy(), g[f"e2e__labels_{i}"]) and np.array_equal(s[i].numpy(), g[f"e2e__scores_{i}"])
+    m.train()
+    locs, scores = m(x)
+    conf, loc = OMB.multibox_loss(locs, scores, boxes, labels, m.priors_cxcycz, [0.1, 0.2])
+    (conf + loc).backward()
+    assert abs(conf.item() - float(g["conf"])) <= 1e-6 * abs(float(g["conf"])) and abs(loc.item() - float(g["loc"])) <= 1e-6 * abs(float(g["loc"]))
+    grads = {k: p_.grad for k, p_ in m.named_parameters() if p_.grad is not None}
+    assert list(grads.keys()) == list(g["grad_names"])
+    for k, norm in zip(g["grad_names"], g["grad_norm"]):
+        assert abs(grads[k].double().norm().item() - norm) <= 1e-5 * max(norm, 1e-6), k

@@ -90,3 +90,36 @@ def test_bucket_policy_keeps_the_exposed_tail_small(n_buckets):
     order = ["heads", 7, 6, 5, 4, 3, 2, 1, 0]
     pos = [order.index(stage_of[k]) for k in range(len(red.ranges))]
     assert pos == sorted(pos) and pos[-2] < pos[-1]
+
+
+def _gather_worker(rank, world, port, result_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mslesions3d_amd.datasets import ShardSampler
+        from mslesions3d_amd.predict import gather_detections
+        from mslesions3d_amd.train import _mean_over_ranks
+        n = 7  # odd: the wrap-around padding makes one subject appear on two ranks
+        mine = ShardSampler(n, rank, world, shuffle=False).indices().tolist()
+        records = [(pos, f"{pos:04d}", {"boxes": [[0.1 * pos] * 6], "rank": rank}) for pos in mine]
+        merged = gather_detections(records, world, rank)
+        if rank == 0:
+            assert [r[0] for r in merged] == list(range(n)) and [r[1] for r in merged] == [f"{i:04d}" for i in range(n)]
+            assert {r[2]["rank"] for r in merged} == {0, 1}
+        else:
+            assert merged is None
+        # validation averages: rank r contributes r + 1 batches whose losses are all (r + 1): mean = (1*1 + 2*2) / 3
+        avg = _mean_over_ranks([float((rank + 1) * (rank + 1)), 0.5 * (rank + 1)], rank + 1, torch.device("cpu"), True)
+        assert abs(avg[0] - 5.0 / 3.0) < 1e-12 and abs(avg[1] - 0.5) < 1e-12
+        open(os.path.join(result_dir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_predict_gather_and_validation_mean_gloo_world2(tmp_path):
+    """inference is replicas-only with the detections gathered on rank 0; train.py's validation averages are one
+    all-reduce so that every rank takes the same early-stopping / checkpoint decisions."""
+    world = 2
+    mp.spawn(_gather_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))

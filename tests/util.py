@@ -16,9 +16,9 @@ def golden(name):
         return {k: z[k] for k in z.files}
 
 
-def oracle_model(input_channels=1, input_size=(64, 64, 64), seed=1234, n_classes=2):
+def oracle_model(input_channels=1, input_size=(64, 64, 64), seed=1234, n_classes=2, feature_ids=(3, 5, 7)):
     """Oracle network carrying the deterministic golden weights (tests/golden/detinit.py)."""
     m = OracleSSD3D(n_classes=n_classes, input_channels=input_channels, input_size=input_size,
-                    emulate_reference_init=False)
+                    emulate_reference_init=False, feature_ids=feature_ids)
     m.load_state_dict(detinit.fill_state_dict(m.state_dict(), seed))
     return m
