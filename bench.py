@@ -38,6 +38,12 @@ def parse():
     ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
                     help="f32: the headline configuration (BASELINE configs[1]); bf16: activations and activation gradients "
                          "stored as bf16, fp32 weights / accumulators / optimiser (BASELINE configs[2])")
+    ap.add_argument("--mode", choices=["train", "infer"], default="train",
+                    help="train: the headline metric (training volumes/s, 128^3 x 4).  infer: BASELINE configs[3] - predict_step "
+                         "(eval forward + decode + 3-D NMS) at 192^3 x 2, volumes/s + kept boxes/s + mAP on synthetic cases")
+    ap.add_argument("--train-steps", type=int, default=300, help="infer mode: optimisation steps before the timed inference "
+                    "(random-init weights never see a cube otherwise; outside the timed region)")
+    ap.add_argument("--map-cases", type=int, default=8, help="infer mode: synthetic cases scored for mAP@0.1 / 0.5")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=25)  # ~10 s of CPU work
     ap.add_argument("--no-aggregate", action="store_true",
@@ -77,8 +83,162 @@ def cpu_baseline(size, batch, channels, steps):
                       f"oracle (plain torch CPU ops), {dt / steps * 1e3:.0f} ms/step"}
 
 
+def cpu_baseline_infer(model, x, steps, kw):
+    """The oracle's predict path (eval forward + detect_objects, kind 'port') on the host cores, on the batch the GPU timed,
+    with the GPU model's weights.  Also returns its detections (prior indices per image) for the parity field."""
+    from oracle import detect as OD
+    from oracle.network import OracleSSD3D
+    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    torch.set_num_threads(cores)
+    size = tuple(x.shape[2:])
+    om = OracleSSD3D(model.n_classes, x.shape[1], size, emulate_reference_init=False)
+    om.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()})
+    om.eval()
+    xc = x.detach().cpu()
+
+    def once():
+        with torch.no_grad():
+            ol, osc = om(xc)
+            return OD.detect_objects(ol, osc, om.priors_cxcycz, kw["min_score"], kw["max_overlap"], kw["top_k"], return_prior_index=True)
+    det = once()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        once()
+    dt = time.perf_counter() - t0
+    n = x.shape[0]
+    return ({"value": round(n * steps / dt, 3), "unit": "volumes/s", "cores": torch.get_num_threads(), "kind": "port",
+             "sample": f"{steps} timed predict passes (+1 warm-up) of the same {size[0]}^3 batch-{n} fp32 workload: oracle eval "
+                       f"forward + detect_objects (plain torch CPU ops), {dt / steps * 1e3:.0f} ms per batch"}, det)
+
+
+def main_infer(args):
+    """BASELINE configs[3]: 192^3, batch 2, predict.py path (LSSD3D.predict_step = eval forward + softmax / decode + per-class
+    candidate selection + 3-D NMS + top-k, ssd3d.py:344-460,692-702) on inputs resident in HBM.  One JSON line."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("MSL_BENCH_BACKEND", "nccl")
+    local = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
+    if world > 1:  # replicas only (SURVEY 8e): no collective on the data path; the process group carries the timing barrier
+        from mslesions3d_amd.parallel import init_distributed
+        init_distributed(backend, rank=rank, world_size=world, device=torch.device("cuda", local) if backend == "nccl" else None)
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    from mslesions3d_amd.ssd3d import LSSD3D
+    from mslesions3d_amd.synth import make_batch_on_device
+    from mslesions3d_amd.trainer import FusedTrainer
+    from mslesions3d_amd.utils import calculate_mAP
+    size = (args.size,) * 3
+    torch.manual_seed(970205)
+    model = LSSD3D(n_classes=2, input_channels=args.channels, input_size=size, threshold=[0.1, 0.2], alpha=1.0, lr=1e-3,
+                   batch_size=args.batch).to(dev).train()
+    # a short optimisation run so that scores and running statistics are not the initial ones (fp32, outside the timed region)
+    tr = FusedTrainer(model)
+    t_tr = time.perf_counter()
+    for s in range(args.train_steps):
+        x, boxes, labels = make_batch_on_device(args.batch, size, dev, args.channels, seed=5000 + s % 64)
+        tr.step(x, boxes, labels, sync=(s == args.train_steps - 1))
+    torch.cuda.synchronize()
+    t_tr = time.perf_counter() - t_tr
+    model.eval()
+    model.compute_dtype = args.dtype
+    kw = dict(min_score=0.3, max_overlap=0.3, top_k=50)
+    model.min_score, model.max_overlap, model.top_k = kw["min_score"], kw["max_overlap"], kw["top_k"]
+    x, gt_boxes, gt_labels = make_batch_on_device(args.batch, size, dev, args.channels, seed=1000 * rank + 3)
+    for _ in range(max(args.warmup, 2)):
+        model.predict_step({"img": x})
+    buf = model.predict_input_buffer(x.shape)  # inputs resident in HBM: the batch lives in predict_step's staging buffer
+    buf.copy_(x)
+    torch.cuda.synchronize()
+    eng = model._engine
+    if not args.no_events:
+        eng.start_profile({"stem_fwd"})
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    nboxes = 0
+    for _ in range(args.steps):
+        out = model.predict_step({"img": buf})
+        nboxes += sum(len(b) for b in out[0])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    prof = eng.stop_profile() if not args.no_events else {}
+    tmax = torch.tensor([dt, 0.0], dtype=torch.float64, device=dev)
+    tsum = torch.tensor([float(nboxes)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+    dt, nboxes = float(tmax[0].item()), float(tsum.item())
+    # mAP on synthetic cases (rank 0; detections of this dtype against the generator's ground truth)
+    det_b, det_l, det_s, tb, tl = [], [], [], [], []
+    for c in range(0, args.map_cases, args.batch):
+        xs, bs, ls = make_batch_on_device(args.batch, size, dev, args.channels, seed=9000 + c)
+        b, l, s_ = model.predict_step({"img": xs})
+        det_b += [t.cpu() for t in b]
+        det_l += [t.cpu() for t in l]
+        det_s += [t.cpu() for t in s_]
+        tb += [t.cpu() for t in bs]
+        tl += [t.cpu() for t in ls]
+    dif = [torch.zeros(len(t), dtype=torch.bool) for t in tl]
+    maps = {}
+    for iou in (0.1, 0.5):
+        d = calculate_mAP(det_b, det_l, det_s, tb, tl, dif, min_overlap=iou, return_detail=True)
+        maps[str(iou)] = {k: round(float(d[k]), 6) for k in ("mAP", "precision", "recall", "f1_score")}
+    if rank == 0:
+        pl = eng.plan_for(buf, False)
+        d0 = pl.dims[0]
+        esz = 4.0 if args.dtype == "f32" else 2.0
+        vol = lambda d: d[0] * d[1] * d[2]
+        alg_bytes = 4.0 * args.batch * args.channels * vol(size) + esz * args.batch * 32 * vol(d0) + 4.0 * 32 * 27 * args.channels
+        ms = prof.get("stem_fwd", [])
+        avg_ms = sum(ms) / max(len(ms), 1)
+        achieved = alg_bytes / (avg_ms * 1e-3) / 1e9 if ms else None
+        out = {
+            "metric": "inference volumes/sec at 192^3 batch-2 (predict_step: eval forward + decode + 3-D NMS), replicas over N MI355X",
+            "value": round(world * args.batch * args.steps / dt, 2), "unit": "volumes/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "boxes_per_s": round(nboxes / dt, 1),
+            "config": {"workload": f"{args.size}^3 synthetic volumes, batch {args.batch}/GPU, {args.channels} channel(s), "
+                                   f"{'fp32' if args.dtype == 'f32' else 'bf16 activations / fp32 weights and accumulators'}, SSD3D+MobileNet3D "
+                                   f"predict_step with 3-D NMS (BASELINE configs[3]), min_score {kw['min_score']}, max_overlap "
+                                   f"{kw['max_overlap']}, top_k {kw['top_k']}; weights: random init + {args.train_steps} fp32 optimisation "
+                                   f"steps on synthetic batches ({t_tr:.1f} s, untimed)",
+                       "global_batch": world * args.batch, "parallelism": f"replicas x{world}", "priors": pl.P},
+            "mAP_synthetic": {"cases": args.map_cases, "IoU": maps,
+                              "note": "detections of this run's dtype against the generator's cube boxes (synth.make_batch_on_device)"},
+            "roofline": {"bound": "hbm", "kernel": "stem forward (dense 3x3x3 s2, 1->32 channels; the longest launch of the pass)",
+                         "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": None if achieved is None else round(achieved / HBM_PEAK_GBS, 4),
+                         "frac_basis": "HIP-event pair around the launch inside the timed predict_step replays",
+                         "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_ms * 1e3, 2),
+                         "launches_timed": len(ms)},
+            "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MSL_")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, odet = cpu_baseline_infer(model, x, max(1, min(args.cpu_steps, 10)), kw)
+            out["cpu_baseline"] = cb
+            model_det = model.detect_objects(*model(x), return_prior_index=True, **kw) if args.dtype == "f32" else None
+            if model_det is not None:
+                same = all(torch.equal(model_det[3][i].cpu(), odet[3][i]) for i in range(args.batch))
+                out["cpu_baseline"]["keep_lists_equal_oracle"] = bool(same)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.mode == "infer":
+        if args.size == 128 and args.batch == 4 and "--size" not in sys.argv and "--batch" not in sys.argv:
+            args.size, args.batch = 192, 2  # configs[3]
+        if "--steps" not in sys.argv:
+            args.steps = 50
+        return main_infer(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
