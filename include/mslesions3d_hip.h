@@ -71,6 +71,19 @@ int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, co
                           const float* invstd, float* dgamma, float* dbeta, float* dy, int N, int C, int S,
                           void* stream);
 
+/* Per-channel backward link of a Block (autograd of mobilenet.py:43-47 between two pointwise GEMMs), one launch instead of
+ * msl_bn_relu_bwd_fused (bn1) + msl_dwconv_bwd_data + msl_bn_relu_bwd_fused (previous block's bn2):
+ *   g_z (N,C,OD,OH,OW): in dL/d relu(bn1(z)), out dL/dz (in place; the depthwise weight gradient reads it)
+ *   g_y (N,C,D,H,W):    out dL/dy_prev; with accumulate != 0 its content (the heads' share, ssd3d.py:143-169 backward) is
+ *                       added to the depthwise bwd-data result before the BatchNorm backward
+ *   vec_z / vec_y: (>= 4, C) BatchNorm vector blocks [scale, shift, mean, invstd] of bn1 (on z) / of the previous bn2 (on y_prev)
+ *   (D,H,W) = input extents of the depthwise layer, stride 1 or 2 (k3, p1).  A channel's whole population lives in one
+ *   workgroup: supported while N*D*H*W <= 16384 per channel (W and OW multiples of 4); else MSL_ERR_UNSUPPORTED (-2). */
+int msl_block_bwd_channel_link_supported(int N, int D, int H, int W, int stride);
+int msl_block_bwd_channel_link(float* g_z, const float* z, const float* vec_z, const float* w_dw, const float* y_prev,
+                               const float* vec_y, float* g_y, float* dgamma_z, float* dbeta_z, float* dgamma_y,
+                               float* dbeta_y, int N, int C, int D, int H, int W, int stride, int accumulate, void* stream);
+
 /* ---- stem: Conv3d(Cin->32,k3,stride (sd,sh,sw),p1,no bias) : mobilenet.py:26-31 via ssd3d.py:60-61 ------- */
 int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW);
 int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D, int H,

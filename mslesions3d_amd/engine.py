@@ -283,6 +283,7 @@ class Engine:
         self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "512"))
         self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", "32"))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
+        self.channel_link = True  # per-channel backward links of the tail blocks in one launch each (csrc/chanlink.hip)
         self.side = {}
         self.arena = None
         self.plans = {}
@@ -1163,6 +1164,7 @@ class Engine:
             self._fork(pl, "bwd_loss_ready", st, stH)
         L = _lib.load()
         pre_np = None  # set when the producer of the next activation gradient also produced its BatchNorm partials
+        linked = False  # set when a channel link already applied the BatchNorm backward of the next layer's output gradient
         pending = []  # side-stream launches, issued one layer late so that the chain's launches always go first
         sinks = []    # (layer, closure) of the weight-gradient launches still to be issued
         tail = []     # blocks whose pointwise weight gradients share one launch (deepest first), and their arguments
@@ -1202,24 +1204,38 @@ class Engine:
             # then the depthwise gradients.  The host enqueues the dependency chain (main stream) FIRST and the two
             # weight gradients (wgrad stream, waiting on events recorded in the chain) afterwards: the chain is made of
             # ~10 us kernels, so any launch queued in front of its next link shows up as idle time.
-            self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st, pre_np=pre_np)
-            pre_np = None
+            if not linked:  # (a channel link of block i+1 has already turned g_y[i] into dL/dy_i)
+                self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st, pre_np=pre_np)
+            pre_np, linked = None, False
             # dL/dy_i is final here: the pointwise weight gradient may start two or three chain kernels before dL/dz_i is
             rec_here = self.wgrad_record_at is None or i in self.wgrad_record_at or i == 1
             ev_dy = self._record(pl, f"dy{i}", st) if ms and self.early_pw_bww and rec_here else None
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
                     sp["cout"], S, st)
-            self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
-            ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
-            if accumulate and (i - 1) in side_feats:
-                self._wait(st, pl.events[f"head_done{i - 1}"])
-            # big producer layers: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
             Sp = pd * ph * pw
             np_red = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, sp["cin"], pd, ph, pw) if (s == 2 and N * Sp > 65536) else -1
             fused_stem = i == 1 and self.fuse_stem and pl.fused_stem_np > 0
+            # tail of the network: BatchNorm1 backward of z_i, depthwise bwd-data (+ the heads' share) and BatchNorm2 backward
+            # of y_{i-1} are all per channel and a channel's population fits one workgroup: ONE launch (csrc/chanlink.hip)
+            link = (self.channel_link and not fused_stem and np_red <= 0
+                    and L.msl_block_bwd_channel_link_supported(N, pd, ph, pw, s) == 1)
+            if not link:
+                self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
+                ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
+            if accumulate and (i - 1) in side_feats:
+                self._wait(st, pl.events[f"head_done{i - 1}"])
+            # big producer layers: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
             ev_red = None
-            if fused_stem:
+            if link:
+                prev = "base.features.0.1" if i == 1 else f"base.features.{i - 1}.bn2"
+                self._k(f"link{i}", "msl_block_bwd_channel_link", ptr(pl.g_z[i]), ptr(pl.z[i]), ptr(pl.bn_z[i]),
+                        ptr(feats[i].conv1.weight), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1]), ptr(pl.g_y[i - 1]),
+                        ptr(gv[name + ".bn1.weight"]), ptr(gv[name + ".bn1.bias"]), ptr(gv[prev + ".weight"]),
+                        ptr(gv[prev + ".bias"]), N, sp["cin"], pd, ph, pw, s, accumulate, st)
+                ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
+                linked = True
+            elif fused_stem:
                 # one pass over (dL/dz_1, y_0): BatchNorm-backward sums of the stem + the depthwise weight gradient;
                 # the stem weight gradient below rebuilds dL/d(stem activation) from dL/dz_1 on the fly
                 vp = pl.bn_y[0]
@@ -1303,8 +1319,9 @@ class Engine:
                 self._k("stem_bww", "msl_stem_conv_bwd_weight_bnapply", ptr(pl.g_y[0]), ptr(pl.y[0]), ptr(pl.bn_y[0]),
                         ptr(pl.saved_input), None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         else:
-            self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st,
-                         pre_np=pre_np)
+            if not linked:  # (tiny inputs: block 1's channel link has already applied the stem's BatchNorm backward)
+                self._bn_bwd(pl.g_y[0], pl.y[0], pl.bn_y[0], "base.features.0.1", N * S0, N, specs[0]["cout"], S0, pl, st,
+                             pre_np=pre_np)
             self._k("stem_bww", "msl_stem_conv_bwd_weight", ptr(pl.g_y[0]), ptr(pl.saved_input),
                     None, ptr(pl.ws_stem), N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
         for fn in pending:

@@ -724,3 +724,73 @@ def test_fused_stem_backward_random_shapes(case):
     """Both halves of the stem backward that never stores dL/d(stem activation), at seeded random even volumes (the fused
     pass needs the stem's output rows to be a multiple of 4 wide; other shapes take the materialising path)."""
     _fused_stem_case(*case)
+
+
+# ------------------------------------------------------------------------------------------------- per-channel backward link
+@pytest.mark.parametrize("n,c,dims,stride,acc", [
+    (4, 512, (4, 4, 4), 1, 1),     # block 7 at 128^3 x 4: one wave per channel, one quad per lane
+    (4, 256, (8, 8, 8), 2, 0),     # block 6: stride 2, four waves, 2 input quads per thread
+    (4, 256, (8, 8, 8), 1, 1),     # block 5 (+ the heads' share of the 8^3 feature map)
+    (4, 128, (16, 16, 16), 2, 1),  # block 4: sixteen waves per channel, 4 input quads per thread
+    (4, 128, (16, 16, 16), 1, 0),  # block 3: sixteen waves, 124 KB of LDS
+    (1, 40, (4, 4, 4), 1, 0),      # ragged: fewer quads than lanes
+    (3, 24, (4, 8, 16), 1, 1),     # odd batch, non-cubic: masked quads
+    (2, 16, (8, 4, 8), 2, 1),      # stride 2 non-cubic
+    (5, 8, (8, 8, 16), 2, 0),      # five images: the last thread's quads are masked
+    (2, 8, (16, 8, 16), 1, 1),     # eight waves
+    (3, 8, (2, 4, 8), 2, 0),       # OD = 1
+])
+def test_block_bwd_channel_link_matches_autograd(n, c, dims, stride, acc):
+    """msl_block_bwd_channel_link against torch autograd of relu(bn1(dwconv(relu(bn2(y))))) (mobilenet.py:43-47 backward,
+    train-mode BatchNorm) + the heads' share of dL/d relu(bn2(y)): dL/dz, dL/dy, dgamma / dbeta of both BatchNorms."""
+    L = _lib.load()
+    D, H, W = dims
+    assert L.msl_block_bwd_channel_link_supported(n, D, H, W, stride) == 1
+    y = rnd(n, c, D, H, W, seed=1).requires_grad_(True)
+    bn2, bn1 = torch.nn.BatchNorm3d(c), torch.nn.BatchNorm3d(c)
+    conv = torch.nn.Conv3d(c, c, 3, stride=stride, padding=1, groups=c, bias=False)
+    with torch.no_grad():
+        for i, bn in enumerate((bn2, bn1)):
+            bn.weight.copy_(torch.rand(c, generator=torch.Generator().manual_seed(10 + i)) + 0.5)
+            bn.bias.copy_(rnd(c, seed=20 + i, scale=0.3))
+        conv.weight.copy_(rnd(c, 1, 3, 3, 3, seed=3, scale=0.3))
+    a_prev = torch.relu(bn2(y))
+    z = conv(a_prev)
+    z.retain_grad()
+    a = torch.relu(bn1(z))
+    G = rnd(*a.shape, seed=4)
+    Hs = rnd(*a_prev.shape, seed=5) if acc else torch.zeros_like(a_prev)
+    ((a * G).sum() + (a_prev * Hs).sum()).backward()
+
+    def vec(x, bn):  # [scale, shift, mean, invstd] of a train-mode BatchNorm on x
+        mean = x.mean(dim=(0, 2, 3, 4))
+        var = x.var(dim=(0, 2, 3, 4), unbiased=False)
+        inv = 1.0 / torch.sqrt(var + bn.eps)
+        sc = bn.weight * inv
+        return torch.stack([sc, bn.bias - mean * sc, mean, inv]).detach()
+    g_z, g_y = K(G), K(Hs if acc else torch.full_like(Hs, 7.0))  # (without accumulate the old content must be ignored)
+    outs = [K(torch.zeros(c)) for _ in range(4)]
+    _lib.call("msl_block_bwd_channel_link", ptr(g_z), ptr(K(z)), ptr(K(vec(z, bn1))), ptr(K(conv.weight)), ptr(K(y)),
+              ptr(K(vec(y, bn2))), ptr(g_y), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), n, c, D, H, W, stride, acc, st())
+    close(g_z, z.grad, 2e-4, 2e-5 * float(z.grad.abs().max()), "dL/dz")
+    close(g_y, y.grad, 2e-4, 2e-5 * float(y.grad.abs().max()), "dL/dy")
+    close(outs[0], bn1.weight.grad, 2e-4, 1e-5 * float(bn1.weight.grad.abs().max()), "dgamma bn1")
+    close(outs[1], bn1.bias.grad, 2e-4, 1e-5 * float(bn1.bias.grad.abs().max()), "dbeta bn1")
+    close(outs[2], bn2.weight.grad, 2e-4, 1e-5 * float(bn2.weight.grad.abs().max()), "dgamma bn2")
+    close(outs[3], bn2.bias.grad, 2e-4, 1e-5 * float(bn2.bias.grad.abs().max()), "dbeta bn2")
+    # run-to-run bit-identical (fixed summation order, no atomics)
+    g_z2, g_y2 = K(G), K(Hs if acc else torch.full_like(Hs, -3.0))
+    _lib.call("msl_block_bwd_channel_link", ptr(g_z2), ptr(K(z)), ptr(K(vec(z, bn1))), ptr(K(conv.weight)), ptr(K(y)),
+              ptr(K(vec(y, bn2))), ptr(g_y2), ptr(outs[0]), ptr(outs[1]), ptr(outs[2]), ptr(outs[3]), n, c, D, H, W, stride, acc, st())
+    assert torch.equal(g_z, g_z2) and torch.equal(g_y, g_y2)
+
+
+def test_block_bwd_channel_link_refuses_what_it_cannot_hold():
+    L = _lib.load()
+    assert L.msl_block_bwd_channel_link_supported(4, 32, 32, 32, 2) == 0   # 32 768 elements per channel
+    assert L.msl_block_bwd_channel_link_supported(4, 6, 6, 6, 1) == 0      # not a power of two (a 192^3 tail)
+    assert L.msl_block_bwd_channel_link_supported(4, 12, 12, 12, 1) == 0
+    assert L.msl_block_bwd_channel_link_supported(2, 4, 4, 4, 2) == 0      # OW = 2
+    x = K(torch.zeros(2 * 8 * 216))
+    rc = L.msl_block_bwd_channel_link(ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), 2, 8, 6, 6, 6, 1, 0, st())
+    assert rc == -2
