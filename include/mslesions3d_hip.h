@@ -77,12 +77,17 @@ int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, co
  *   g_y (N,C,D,H,W):    out dL/dy_prev; with accumulate != 0 its content (the heads' share, ssd3d.py:143-169 backward) is
  *                       added to the depthwise bwd-data result before the BatchNorm backward
  *   vec_z / vec_y: (>= 4, C) BatchNorm vector blocks [scale, shift, mean, invstd] of bn1 (on z) / of the previous bn2 (on y_prev)
- *   (D,H,W) = input extents of the depthwise layer, stride 1 or 2 (k3, p1).  A channel's whole population lives in one
- *   workgroup: supported while N*D*H*W <= 16384 per channel (W and OW multiples of 4); else MSL_ERR_UNSUPPORTED (-2). */
+ *   dw_dw (C,27) or NULL: if given, the depthwise weight gradient dL/dw_dw (mobilenet.py:38 backward) is produced as well
+ *                       (same operand pairs as the transposed convolution) - msl_dwconv_bwd_weight is then not needed
+ *   (D,H,W) = input extents of the depthwise layer (powers of two, W >= 4, OW >= 4), stride 1 or 2 (k3, p1).  A channel's
+ *   whole population lives in one workgroup: supported while N*D*H*W <= 16384 per channel; else MSL_ERR_UNSUPPORTED (-2).
+ *   _supported returns the number of waves per channel the launch would use (1, 4, 8 or 16), 0 if unsupported: with
+ *   many waves per channel the kernel is bound by instruction issue and dw_dw is better left to its own launch. */
 int msl_block_bwd_channel_link_supported(int N, int D, int H, int W, int stride);
 int msl_block_bwd_channel_link(float* g_z, const float* z, const float* vec_z, const float* w_dw, const float* y_prev,
                                const float* vec_y, float* g_y, float* dgamma_z, float* dbeta_z, float* dgamma_y,
-                               float* dbeta_y, int N, int C, int D, int H, int W, int stride, int accumulate, void* stream);
+                               float* dbeta_y, float* dw_dw, int N, int C, int D, int H, int W, int stride, int accumulate,
+                               void* stream);
 
 /* ---- stem: Conv3d(Cin->32,k3,stride (sd,sh,sw),p1,no bias) : mobilenet.py:26-31 via ssd3d.py:60-61 ------- */
 int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW);

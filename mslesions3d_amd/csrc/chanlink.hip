@@ -44,12 +44,14 @@ __device__ __forceinline__ void chan_sum2(double& a, double& b, double* scratch)
 // Extents are powers of two (lD, lH, lW = log2 of the INPUT extents): every index split is a shift or a mask - with one to
 // four waves per SIMD these kernels are bound by the number of instructions a wave issues, not by memory.
 // LDS image of dL/dz: [N][OD+2][OH+2][OW+8] floats, a row's data at columns 4 .. OW+3 (16-byte aligned), zero elsewhere.
-template <int NW, int QO, int QI, int STRIDE>
+// BWW: the link also produces the depthwise WEIGHT gradient dW[c][k] = sum_i relu(bn2(y))[i] * dL/dz[(i + 1 - k) / s] (the very
+// operand pairs of the transposed convolution: one more FMA per pair) - the weight-gradient launch of the block disappears.
+template <int NW, int QO, int QI, int STRIDE, bool BWW>
 __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
     float* __restrict__ g_z, const float* __restrict__ z, const float* __restrict__ vec_z, const float* __restrict__ w_dw,
     const float* __restrict__ y_prev, const float* __restrict__ vec_y, float* __restrict__ g_y,
     float* __restrict__ dgamma_z, float* __restrict__ dbeta_z, float* __restrict__ dgamma_y, float* __restrict__ dbeta_y,
-    int N, int C, int lD, int lH, int lW, int accumulate) {
+    float* __restrict__ dw_dw, int N, int C, int lD, int lH, int lW, int accumulate) {
   constexpr int NT = NW * 64, LS = STRIDE == 2 ? 1 : 0;
   extern __shared__ __align__(16) float lds[];
   const int c = blockIdx.x, tid = threadIdx.x;
@@ -58,7 +60,8 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
   const int lSo = lOD + lOH + lOW, lSi = lD + lH + lW;       // log2 elements per (image, channel)
   const int tot_qo = N << (lSo - 2), tot_qi = N << (lSi - 2);
   const int PW = OW + 8, PP = (OH + 2) * PW, pimg = (OD + 2) * PP, ptot = N * pimg;  // multiples of 4
-  double* scratch = reinterpret_cast<double*>(lds + ptot);
+  // (BWW: the image region is reused for the 27 x NT tap-gradient exchange once the gather is done)
+  double* scratch = reinterpret_cast<double*>(lds + (BWW ? max(ptot, 27 * NT + 27 * 4) : ptot));
 
   // ---- every global load of the link, back to back (clamped addresses, masked later) -------------------------------
   f32x4v gq[QO], zq[QO], yq[QI], aq[QI];
@@ -137,6 +140,9 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
   s1 = 0.f;
   s2 = 0.f;
   const int W = 1 << lW, H = 1 << lH;
+  float dwa[BWW ? 27 : 1];
+#pragma unroll
+  for (int k = 0; k < (BWW ? 27 : 1); ++k) dwa[k] = 0.f;
 #pragma unroll
   for (int q = 0; q < QI; ++q) {
     const int qi = tid + q * NT;
@@ -144,6 +150,9 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
     const int qc = in ? qi : 0, n = qc >> (lSi - 2), r = qc & ((1 << (lSi - 2)) - 1);
     const int s = 4 * r, iw = s & (W - 1), ih = (s >> lW) & (H - 1), id = s >> (lW + lH);
     f32x4v acc = aq[q];
+    f32x4v av;  // the block's input activation relu(bn2(y_{i-1})) at the quad (zero for a masked quad)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) av[e] = (BWW && in) ? msl::act(yq[q][e], sc2, sh2) : 0.f;
     const float* img = lds + n * pimg + 4;  // (+4: the data columns of a row)
 #pragma unroll
     for (int kd = 0; kd < 3; ++kd) {
@@ -165,6 +174,14 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
           acc[1] = fmaf(w0, m[2], fmaf(w1, m[1], fmaf(w2, m[0], acc[1])));
           acc[2] = fmaf(w0, m[3], fmaf(w1, m[2], fmaf(w2, m[1], acc[2])));
           acc[3] = fmaf(w0, rgt, fmaf(w1, m[3], fmaf(w2, m[2], acc[3])));
+          if (BWW) {
+            float& d0 = dwa[kd * 9 + kh * 3];
+            float& d1 = dwa[kd * 9 + kh * 3 + 1];
+            float& d2 = dwa[kd * 9 + kh * 3 + 2];
+            d0 = fmaf(av[0], m[1], fmaf(av[1], m[2], fmaf(av[2], m[3], fmaf(av[3], rgt, d0))));
+            d1 = fmaf(av[0], m[0], fmaf(av[1], m[1], fmaf(av[2], m[2], fmaf(av[3], m[3], d1))));
+            d2 = fmaf(av[0], lft, fmaf(av[1], m[0], fmaf(av[2], m[1], fmaf(av[3], m[2], d2))));
+          }
         } else {
           // input column w = iw + j: even -> tap 1 of output w/2; odd -> tap 0 of output (w+1)/2 and tap 2 of output (w-1)/2
           const int o = iw >> 1;  // even: an 8-byte aligned pair + one more column
@@ -174,6 +191,14 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
           acc[1] = fmaf(w0, r01.y, fmaf(w2, r01.x, acc[1]));
           acc[2] = fmaf(w1, r01.y, acc[2]);
           acc[3] = fmaf(w0, r2, fmaf(w2, r01.y, acc[3]));
+          if (BWW) {
+            float& d0 = dwa[kd * 9 + kh * 3];
+            float& d1 = dwa[kd * 9 + kh * 3 + 1];
+            float& d2 = dwa[kd * 9 + kh * 3 + 2];
+            d0 = fmaf(av[1], r01.y, fmaf(av[3], r2, d0));
+            d1 = fmaf(av[0], r01.x, fmaf(av[2], r01.y, d1));
+            d2 = fmaf(av[1], r01.x, fmaf(av[3], r01.y, d2));
+          }
         }
       }
     }
@@ -185,6 +210,32 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
       yq[q][e] = xh;
       s1 += gm;
       s2 += gm * xh;
+    }
+  }
+  if (BWW) {
+    // 27 tap sums over the workgroup: transposed through LDS ([k][thread], over the image, which every wave has finished
+    // reading once the barrier below is passed), 4 x 27 threads add a quarter of the threads each in thread order, 27 finish
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 27; ++k) lds[k * NT + tid] = dwa[k];
+    __syncthreads();
+    constexpr int PART = NT / 4;
+    for (int t = tid; t < 108; t += NT) {  // (NT is a multiple of 64: the four quarters of a tap stay in one lane quad)
+      const int k = t >> 2, part = t & 3;
+      const f32x4v* src = reinterpret_cast<const f32x4v*>(lds + k * NT + part * PART);
+      double sum = 0.0;
+#pragma unroll 4
+      for (int i = 0; i < PART / 4; ++i) {
+        const f32x4v v = src[i];
+        sum += (double)v[0];
+        sum += (double)v[1];
+        sum += (double)v[2];
+        sum += (double)v[3];
+      }
+      // the four quarters of a tap sit in neighbouring lanes: quad sum by DPP, fixed order
+      sum += msl::dpp_mov<0xB1>(sum);
+      sum += msl::dpp_mov<0x4E>(sum);
+      if (part == 0) dw_dw[c * 27 + k] = (float)sum;
     }
   }
   t1 = (double)s1;
@@ -242,7 +293,7 @@ bool link_plan(int N, int D, int H, int W, int stride, LinkPlan& p) {
   p.qo = up((tqo + nt - 1) / nt);
   if (p.qo > 1) p.qo = p.qi;  // instantiated: QO == 1 or QO == QI
   const size_t ptot = (size_t)N * (OD + 2) * (OH + 2) * (OW + 8);
-  p.smem = ptot * 4 + 2 * p.nw * sizeof(double);
+  p.smem = std::max(ptot, (size_t)27 * nt + 27 * 4) * 4 + 2 * p.nw * sizeof(double);
   return p.smem <= 156 * 1024;
 }
 
@@ -252,22 +303,30 @@ extern "C" {
 
 int msl_block_bwd_channel_link_supported(int N, int D, int H, int W, int stride) {
   LinkPlan p;
-  return link_plan(N, D, H, W, stride, p) ? 1 : 0;
+  return link_plan(N, D, H, W, stride, p) ? p.nw : 0;  // waves per channel (1, 4, 8, 16); 0: not supported
 }
 
 int msl_block_bwd_channel_link(float* g_z, const float* z, const float* vec_z, const float* w_dw, const float* y_prev,
                                const float* vec_y, float* g_y, float* dgamma_z, float* dbeta_z, float* dgamma_y,
-                               float* dbeta_y, int N, int C, int D, int H, int W, int stride, int accumulate, void* stream) {
+                               float* dbeta_y, float* dw_dw, int N, int C, int D, int H, int W, int stride, int accumulate,
+                               void* stream) {
   if (N <= 0 || C <= 0 || !g_z || !z || !vec_z || !w_dw || !y_prev || !vec_y || !g_y) return MSL_ERR_ARG;
   LinkPlan p;
   if (!link_plan(N, D, H, W, stride, p)) return MSL_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
 #define MSL_LINK_S(NW_, QO_, QI_, S_)                                                                                     \
   do {                                                                                                                   \
-    auto k = block_bwd_channel_link_kernel<NW_, QO_, QI_, S_>;                                                           \
-    if (p.smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem); \
-    hipLaunchKernelGGL(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
-                       dgamma_y, dbeta_y, N, C, p.lD, p.lH, p.lW, accumulate);                                            \
+    if (dw_dw) {                                                                                                         \
+      auto k = block_bwd_channel_link_kernel<NW_, QO_, QI_, S_, true>;                                                   \
+      if (p.smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem); \
+      hipLaunchKernelGGL(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
+                         dgamma_y, dbeta_y, dw_dw, N, C, p.lD, p.lH, p.lW, accumulate);                                   \
+    } else {                                                                                                             \
+      auto k = block_bwd_channel_link_kernel<NW_, QO_, QI_, S_, false>;                                                  \
+      if (p.smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem); \
+      hipLaunchKernelGGL(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
+                         dgamma_y, dbeta_y, dw_dw, N, C, p.lD, p.lH, p.lW, accumulate);                                   \
+    }                                                                                                                    \
   } while (0)
 #define MSL_LINK_Q(NW_, S_)                                            \
   do {                                                                 \

@@ -231,6 +231,7 @@ class Plan:
         self.events = {}
         self.saved_input = None
         self.generation = 0
+        self.dw_in_link = set()  # blocks whose depthwise weight gradient a channel link writes (no partials to fold)
 
 
 class Engine:
@@ -1218,8 +1219,10 @@ class Engine:
             fused_stem = i == 1 and self.fuse_stem and pl.fused_stem_np > 0
             # tail of the network: BatchNorm1 backward of z_i, depthwise bwd-data (+ the heads' share) and BatchNorm2 backward
             # of y_{i-1} are all per channel and a channel's population fits one workgroup: ONE launch (csrc/chanlink.hip)
-            link = (self.channel_link and not fused_stem and np_red <= 0
-                    and L.msl_block_bwd_channel_link_supported(N, pd, ph, pw, s) == 1)
+            link_nw = L.msl_block_bwd_channel_link_supported(N, pd, ph, pw, s) if self.channel_link else 0
+            link = link_nw > 0 and not fused_stem and np_red <= 0
+            # (with <= 4 waves per channel the link takes the depthwise weight gradient along: no launch for it below)
+            link_bww = link and link_nw <= 4
             if not link:
                 self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
                 ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
@@ -1232,7 +1235,10 @@ class Engine:
                 self._k(f"link{i}", "msl_block_bwd_channel_link", ptr(pl.g_z[i]), ptr(pl.z[i]), ptr(pl.bn_z[i]),
                         ptr(feats[i].conv1.weight), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1]), ptr(pl.g_y[i - 1]),
                         ptr(gv[name + ".bn1.weight"]), ptr(gv[name + ".bn1.bias"]), ptr(gv[prev + ".weight"]),
-                        ptr(gv[prev + ".bias"]), N, sp["cin"], pd, ph, pw, s, accumulate, st)
+                        ptr(gv[prev + ".bias"]), ptr(gv[name + ".conv1.weight"]) if link_bww else None, N, sp["cin"], pd, ph,
+                        pw, s, accumulate, st)
+                if link_bww:
+                    pl.dw_in_link.add(i)
                 ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
                 linked = True
             elif fused_stem:
@@ -1252,8 +1258,8 @@ class Engine:
             else:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
-            def wgrads(ev_dz, i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, fused_stem=fused_stem, ev_red=ev_red,
-                       ev_dy=ev_dy):
+            def wgrads(ev_dz, i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, fused_stem=fused_stem or link_bww,
+                       ev_red=ev_red, ev_dy=ev_dy):
                 # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there
                 streams = [stW, stH, stX]
                 sX = streams[i % (self.split_wgrad + 1)] if ms else st
@@ -1274,7 +1280,7 @@ class Engine:
                 if ms and ev_dy is not None:
                     self._wait(sX, ev_dz)
                 if fused_stem:
-                    return  # its partials came with the fused stem backward pass (pl.partials_wf)
+                    return  # its partials came with the fused stem backward pass (pl.partials_wf) / the channel link wrote dW
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
                         ptr(pl.bn_y[i - 1][1]), None, ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, sX)
 
@@ -1379,7 +1385,7 @@ class Engine:
                 cnt = specs[i]["cin"] * specs[i]["cout"]
                 if want(name + ".conv2.weight") and pl.pw_nslabs[i] > 1:
                     rows.append((0, pl.pw_slabs[i], gv[name + ".conv2.weight"], None, pl.pw_nslabs[i], cnt, cnt, 0, 0, 0))
-                if want(name + ".conv1.weight"):
+                if want(name + ".conv1.weight") and i not in getattr(pl, "dw_in_link", ()):  # (a channel link wrote it)
                     if i == 1 and fused:
                         rows.append((1, pl.partials_wf, gv[name + ".conv1.weight"], None, pl.fused_stem_np, specs[i]["cin"] * 27, 0, 0, 0, 0))
                     else:
