@@ -264,6 +264,11 @@ int msl_bn_relu_bwd_reduce_bf16(const void* g, const void* y, const float* scale
 int msl_bn_relu_bwd_apply_bf16(const void* g, const void* y, const float* vec, void* dy, int N, int C, int S, void* stream);
 int msl_bn_relu_bwd_fused_bf16(const void* g, const void* y, const float* vec, float* dgamma, float* dbeta, void* dy, int N,
                                int C, int S, void* stream);
+/* msl_block_bwd_channel_link on bf16 activation / activation-gradient tensors (g_z, z, y_prev, g_y); vectors, taps, sums fp32 */
+int msl_block_bwd_channel_link_bf16(void* g_z, const void* z, const float* vec_z, const float* w_dw, const void* y_prev,
+                                    const float* vec_y, void* g_y, float* dgamma_z, float* dbeta_z, float* dgamma_y,
+                                    float* dbeta_y, float* dw_dw, int N, int C, int D, int H, int W, int stride, int accumulate,
+                                    void* stream);
 int msl_head_conv_bwd_data_bf16(const float* dO_pad, const float* Wb, void* g_a_bf16, int N, int C, int D, int H, int W,
                                 int ncls, void* stream);
 int msl_head_conv_bwd_weight_bf16(const float* dO_pad, const void* a_cl, float* dloc_w, float* dcl_w, float* dloc_b,

@@ -105,6 +105,7 @@ _SIGNATURES = {
     "msl_bn_relu_bwd_reduce_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_bn_relu_bwd_apply_bf16": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_bn_relu_bwd_fused_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "msl_block_bwd_channel_link_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_head_conv_bwd_data_bf16": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_head_conv_bwd_weight_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_stem_conv_bwd_weight_bnapply_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

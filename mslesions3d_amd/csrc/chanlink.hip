@@ -17,6 +17,20 @@ namespace {
 
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
+// activation tensors are fp32 or bf16 in HBM (T = float / msl::su16, the bf16 activation path); all arithmetic is fp32
+template <typename T>
+__device__ __forceinline__ f32x4v ldq(const T* p) {
+  const float4 v = msl::ld4(p);
+  return (f32x4v){v.x, v.y, v.z, v.w};
+}
+template <typename T>
+__device__ __forceinline__ void stq(T* p, f32x4v v) { msl::st4(p, make_float4(v[0], v[1], v[2], v[3])); }
+template <typename T>
+__device__ __forceinline__ f32x4v rounded(const T* tag, f32x4v v) {  // what a later pass would read back from storage
+  const float4 r = msl::as_stored(tag, make_float4(v[0], v[1], v[2], v[3]));
+  return (f32x4v){r.x, r.y, r.z, r.w};
+}
+
 // sum of (a, b) over the workgroup, result in every thread.  NW == 1: DPP / readlane only.
 template <int NW>
 __device__ __forceinline__ void chan_sum2(double& a, double& b, double* scratch) {
@@ -46,10 +60,10 @@ __device__ __forceinline__ void chan_sum2(double& a, double& b, double* scratch)
 // LDS image of dL/dz: [N][OD+2][OH+2][OW+8] floats, a row's data at columns 4 .. OW+3 (16-byte aligned), zero elsewhere.
 // BWW: the link also produces the depthwise WEIGHT gradient dW[c][k] = sum_i relu(bn2(y))[i] * dL/dz[(i + 1 - k) / s] (the very
 // operand pairs of the transposed convolution: one more FMA per pair) - the weight-gradient launch of the block disappears.
-template <int NW, int QO, int QI, int STRIDE, bool BWW>
+template <typename T, int NW, int QO, int QI, int STRIDE, bool BWW>
 __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
-    float* __restrict__ g_z, const float* __restrict__ z, const float* __restrict__ vec_z, const float* __restrict__ w_dw,
-    const float* __restrict__ y_prev, const float* __restrict__ vec_y, float* __restrict__ g_y,
+    T* __restrict__ g_z, const T* __restrict__ z, const float* __restrict__ vec_z, const float* __restrict__ w_dw,
+    const T* __restrict__ y_prev, const float* __restrict__ vec_y, T* __restrict__ g_y,
     float* __restrict__ dgamma_z, float* __restrict__ dbeta_z, float* __restrict__ dgamma_y, float* __restrict__ dbeta_y,
     float* __restrict__ dw_dw, int N, int C, int lD, int lH, int lW, int accumulate) {
   constexpr int NT = NW * 64, LS = STRIDE == 2 ? 1 : 0;
@@ -69,19 +83,19 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
   for (int q = 0; q < QO; ++q) {
     const int qi = min(tid + q * NT, tot_qo - 1), n = qi >> (lSo - 2), r = qi & ((1 << (lSo - 2)) - 1);
     const size_t off = (((size_t)n * C + c) << lSo) + 4 * r;
-    gq[q] = *reinterpret_cast<const f32x4v*>(g_z + off);
-    zq[q] = *reinterpret_cast<const f32x4v*>(z + off);
+    gq[q] = ldq(g_z + off);
+    zq[q] = ldq(z + off);
   }
 #pragma unroll
   for (int q = 0; q < QI; ++q) {
     const int qi = min(tid + q * NT, tot_qi - 1), n = qi >> (lSi - 2), r = qi & ((1 << (lSi - 2)) - 1);
-    yq[q] = *reinterpret_cast<const f32x4v*>(y_prev + (((size_t)n * C + c) << lSi) + 4 * r);
+    yq[q] = ldq(y_prev + (((size_t)n * C + c) << lSi) + 4 * r);
   }
   if (accumulate) {  // (uniform branch around the whole group: the loads still leave back to back)
 #pragma unroll
     for (int q = 0; q < QI; ++q) {
       const int qi = min(tid + q * NT, tot_qi - 1), n = qi >> (lSi - 2), r = qi & ((1 << (lSi - 2)) - 1);
-      aq[q] = *reinterpret_cast<const f32x4v*>(g_y + (((size_t)n * C + c) << lSi) + 4 * r);
+      aq[q] = ldq(g_y + (((size_t)n * C + c) << lSi) + 4 * r);
     }
   } else {
 #pragma unroll
@@ -128,7 +142,8 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
         f32x4v dz;
 #pragma unroll
         for (int e = 0; e < 4; ++e) dz[e] = sc1 * (gq[q][e] - k1 - zq[q][e] * k2);
-        *reinterpret_cast<f32x4v*>(g_z + (((size_t)n * C + c) << lSo) + 4 * r) = dz;  // dL/dz_i: the depthwise weight gradient reads it
+        stq(g_z + (((size_t)n * C + c) << lSo) + 4 * r, dz);  // dL/dz_i: the depthwise weight gradient reads it
+        dz = rounded(g_z, dz);  // (bf16 storage: the transposed convolution sees what a separate launch would read back)
         const int s = 4 * r, ow = s & (OW - 1), oh = (s >> lOW) & (OH - 1), od = s >> (lOW + lOH);
         *reinterpret_cast<f32x4v*>(lds + n * pimg + (od + 1) * PP + (oh + 1) * PW + 4 + ow) = dz;
       }
@@ -202,6 +217,7 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
         }
       }
     }
+    acc = rounded(g_y, acc);  // (bf16 storage: dL/d relu(bn2(y)) as the separate depthwise launch stores it)
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float gm = (in && fmaf(yq[q][e], sc2, sh2) > 0.f) ? acc[e] : 0.f;
@@ -255,7 +271,7 @@ __global__ __launch_bounds__(NW * 64) void block_bwd_channel_link_kernel(
       f32x4v dy;
 #pragma unroll
       for (int e = 0; e < 4; ++e) dy[e] = sc2 * (aq[q][e] - k1 - yq[q][e] * k2);
-      *reinterpret_cast<f32x4v*>(g_y + (((size_t)n * C + c) << lSi) + 4 * r) = dy;
+      stq(g_y + (((size_t)n * C + c) << lSi) + 4 * r, dy);
     }
   }
 }
@@ -299,34 +315,30 @@ bool link_plan(int N, int D, int H, int W, int stride, LinkPlan& p) {
 
 }  // namespace
 
-extern "C" {
-
-int msl_block_bwd_channel_link_supported(int N, int D, int H, int W, int stride) {
+extern "C" int msl_block_bwd_channel_link_supported(int N, int D, int H, int W, int stride) {
   LinkPlan p;
   return link_plan(N, D, H, W, stride, p) ? p.nw : 0;  // waves per channel (1, 4, 8, 16); 0: not supported
 }
 
-int msl_block_bwd_channel_link(float* g_z, const float* z, const float* vec_z, const float* w_dw, const float* y_prev,
-                               const float* vec_y, float* g_y, float* dgamma_z, float* dbeta_z, float* dgamma_y,
-                               float* dbeta_y, float* dw_dw, int N, int C, int D, int H, int W, int stride, int accumulate,
-                               void* stream) {
+template <typename T>
+static int link_launch(T* g_z, const T* z, const float* vec_z, const float* w_dw, const T* y_prev, const float* vec_y, T* g_y,
+                       float* dgamma_z, float* dbeta_z, float* dgamma_y, float* dbeta_y, float* dw_dw, int N, int C, int D,
+                       int H, int W, int stride, int accumulate, void* stream) {
   if (N <= 0 || C <= 0 || !g_z || !z || !vec_z || !w_dw || !y_prev || !vec_y || !g_y) return MSL_ERR_ARG;
   LinkPlan p;
   if (!link_plan(N, D, H, W, stride, p)) return MSL_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-#define MSL_LINK_S(NW_, QO_, QI_, S_)                                                                                     \
+#define MSL_LINK_B(NW_, QO_, QI_, S_, B_)                                                                                 \
   do {                                                                                                                   \
-    if (dw_dw) {                                                                                                         \
-      auto k = block_bwd_channel_link_kernel<NW_, QO_, QI_, S_, true>;                                                   \
-      if (p.smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem); \
-      hipLaunchKernelGGL(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
-                         dgamma_y, dbeta_y, dw_dw, N, C, p.lD, p.lH, p.lW, accumulate);                                   \
-    } else {                                                                                                             \
-      auto k = block_bwd_channel_link_kernel<NW_, QO_, QI_, S_, false>;                                                  \
-      if (p.smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem); \
-      hipLaunchKernelGGL(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
-                         dgamma_y, dbeta_y, dw_dw, N, C, p.lD, p.lH, p.lW, accumulate);                                   \
-    }                                                                                                                    \
+    auto k = block_bwd_channel_link_kernel<T, NW_, QO_, QI_, S_, B_>;                                                    \
+    if (p.smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem); \
+    hipLaunchKernelGGL(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
+                       dgamma_y, dbeta_y, dw_dw, N, C, p.lD, p.lH, p.lW, accumulate);                                     \
+  } while (0)
+#define MSL_LINK_S(NW_, QO_, QI_, S_)                  \
+  do {                                                 \
+    if (dw_dw) MSL_LINK_B(NW_, QO_, QI_, S_, true);    \
+    else MSL_LINK_B(NW_, QO_, QI_, S_, false);         \
   } while (0)
 #define MSL_LINK_Q(NW_, S_)                                            \
   do {                                                                 \
@@ -348,8 +360,29 @@ int msl_block_bwd_channel_link(float* g_z, const float* z, const float* vec_z, c
 #undef MSL_LINK
 #undef MSL_LINK_Q
 #undef MSL_LINK_S
+#undef MSL_LINK_B
   MSL_LAUNCH_CHECK();
   return MSL_OK;
+}
+
+extern "C" {
+
+int msl_block_bwd_channel_link(float* g_z, const float* z, const float* vec_z, const float* w_dw, const float* y_prev,
+                               const float* vec_y, float* g_y, float* dgamma_z, float* dbeta_z, float* dgamma_y,
+                               float* dbeta_y, float* dw_dw, int N, int C, int D, int H, int W, int stride, int accumulate,
+                               void* stream) {
+  return link_launch<float>(g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, dgamma_y, dbeta_y, dw_dw, N, C, D, H, W,
+                            stride, accumulate, stream);
+}
+
+// the same on bf16 activation / activation-gradient tensors (bf16 activation path; BatchNorm vectors, taps, all sums fp32/fp64)
+int msl_block_bwd_channel_link_bf16(void* g_z, const void* z, const float* vec_z, const float* w_dw, const void* y_prev,
+                                    const float* vec_y, void* g_y, float* dgamma_z, float* dbeta_z, float* dgamma_y,
+                                    float* dbeta_y, float* dw_dw, int N, int C, int D, int H, int W, int stride, int accumulate,
+                                    void* stream) {
+  return link_launch<msl::su16>((msl::su16*)g_z, (const msl::su16*)z, vec_z, w_dw, (const msl::su16*)y_prev, vec_y,
+                                (msl::su16*)g_y, dgamma_z, dbeta_z, dgamma_y, dbeta_y, dw_dw, N, C, D, H, W, stride, accumulate,
+                                stream);
 }
 
 }  // extern "C"

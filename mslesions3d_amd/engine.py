@@ -526,19 +526,26 @@ class Engine:
                 if want_features:
                     plain = torch.empty((N, sp["cout"], D, H, W), dtype=torch.float32, device=x.device)
                     out_feats[i] = plain
-                if folds(pl.np_y[i]):
-                    self._k(f"materialize{i}", "msl_bn_relu_materialize_fold", ptr(pl.y[i]), ptr(pl.part_y[i]), pl.np_y[i],
-                            float(N * S), ptr(blk.bn2.weight), ptr(blk.bn2.bias), blk.bn2.eps, ptr(plain), ptr(pl.fpad[i]),
-                            N, sp["cout"], D, H, W, st)
-                else:
-                    self._k(f"materialize{i}", "msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
-                            ptr(pl.bn_y[i][1]), ptr(plain), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
-                # this scale's head convolution only needs the feature map: run it beside the remaining blocks
+
+                def materialize(s_, i=i, sp=sp, blk=blk, plain=plain, D=D, H=H, W=W, S=S):
+                    if folds(pl.np_y[i]):
+                        self._k(f"materialize{i}", "msl_bn_relu_materialize_fold", ptr(pl.y[i]), ptr(pl.part_y[i]), pl.np_y[i],
+                                float(N * S), ptr(blk.bn2.weight), ptr(blk.bn2.bias), blk.bn2.eps, ptr(plain), ptr(pl.fpad[i]),
+                                N, sp["cout"], D, H, W, s_)
+                    else:
+                        self._k(f"materialize{i}", "msl_bn_relu_materialize", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
+                                ptr(pl.bn_y[i][1]), ptr(plain), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, s_)
+                # this scale's head convolution only needs the feature map: run it beside the remaining blocks - and with it
+                # the zero-haloed activation copy it reads (nothing on the chain reads that copy: the next depthwise layer
+                # re-creates the activation from the raw output itself), when the BatchNorm is folded from the partials
+                # (an unfolded one is finalised on the chain first, so its vectors are ready on either stream)
                 last = i == len(specs) - 1
                 if self.multi_stream and not last:
                     ev = self._record(pl, f"fwd_feat{i}", st)
-                    deferred.append(lambda ev=ev, i=i: (self._wait(stH, ev), self._head_forward(pl, i, stH)))
+                    deferred.append(lambda ev=ev, i=i, materialize=materialize: (self._wait(stH, ev), materialize(stH),
+                                                                               self._head_forward(pl, i, stH)))
                 else:
+                    materialize(st)
                     if ev_pack is not None:  # this scale's convolution runs on the chain: the packed weights come from stH
                         self._wait(st, ev_pack)
                         ev_pack = None
@@ -668,6 +675,7 @@ class Engine:
                     pl.g_y[0] = None  # never materialised
             pl.partials = torch.empty(bnp, **f64)
             pl.grad_tables = {}
+            pl.dw_in_link = set()
         self.plans[key] = pl
         return pl
 
@@ -822,7 +830,7 @@ class Engine:
         dlocs, dscores = dlocs.contiguous(), dscores.contiguous()
         last = len(specs) - 1
         L = _lib.load()
-        pre_np = None
+        pre_np, linked = None, False
         if last not in pl.feat_ids:
             raise RuntimeError("the last backbone feature must feed a head")
         wanted = getattr(on_bucket_ready, "stages", None)
@@ -861,21 +869,40 @@ class Engine:
             pd, ph, pw = pl.dims[i - 1]
             s = sp["stride"][0]
             name = f"base.features.{i}"
-            self._bn_bwd_bf16(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N, sp["cout"], S, pl, st, pre_np=pre_np)
-            pre_np = None
+            if not linked:  # (a channel link of block i+1 has already turned g_y[i] into dL/dy_i)
+                self._bn_bwd_bf16(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N, sp["cout"], S, pl, st, pre_np=pre_np)
+            pre_np, linked = None, False
             self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data_bf16", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N,
                     sp["cin"], sp["cout"], S, st)
-            self._bn_bwd_bf16(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N, sp["cin"], S, pl, st)
+            accumulate = 1 if (i - 1) in pl.feat_ids else 0  # the heads already wrote their share
+            Sp = pd * ph * pw
+            fused_stem = i == 1 and pl.fused_stem_np > 0
+            big_producer = s == 2 and pw % 4 == 0 and not self._bn_bwd_bf16_fused(N, Sp)
+            # the per-channel link of the tail blocks in one launch, as in the fp32 step (csrc/chanlink.hip on bf16 storage)
+            link_nw = L.msl_block_bwd_channel_link_supported(N, pd, ph, pw, s) if self.channel_link else 0
+            link = link_nw > 0 and not fused_stem and not big_producer and i >= 2
+            link_bww = link and link_nw <= 4
+            if not link:
+                self._bn_bwd_bf16(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N, sp["cin"], S, pl, st)
+            if accumulate and (i - 1) in side_feats:
+                self._wait(st, pl.events[f"head_done{i - 1}"])
+            if link:
+                prev = f"base.features.{i - 1}.bn2"
+                self._k(f"link{i}", "msl_block_bwd_channel_link_bf16", ptr(pl.g_z[i]), ptr(pl.z[i]), ptr(pl.bn_z[i]),
+                        ptr(feats[i].conv1.weight), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1]), ptr(pl.g_y[i - 1]),
+                        ptr(gv[name + ".bn1.weight"]), ptr(gv[name + ".bn1.bias"]), ptr(gv[prev + ".weight"]),
+                        ptr(gv[prev + ".bias"]), ptr(gv[name + ".conv1.weight"]) if link_bww else None, N, sp["cin"], pd, ph,
+                        pw, s, accumulate, st)
+                linked = True
+                if link_bww:
+                    pl.dw_in_link.add(i)
             sX = st
             if ms:  # both weight gradients of the block on a side stream, once dL/dy_i and dL/dz_i are final
                 sX = stW if i % 2 else stH
                 self._wait(sX, self._record(pl, f"dz{i}", st))
-            accumulate = 1 if (i - 1) in pl.feat_ids else 0  # the heads already wrote their share
-            if accumulate and (i - 1) in side_feats:
-                self._wait(st, pl.events[f"head_done{i - 1}"])
-            Sp = pd * ph * pw
-            fused_stem = i == 1 and pl.fused_stem_np > 0
-            if fused_stem:
+            if link:
+                pass
+            elif fused_stem:
                 # one pass over (dL/dz_1, y_0): the stem's BatchNorm-backward sums + this block's depthwise weight gradient;
                 # the stem weight gradient below rebuilds dL/d(stem activation) from dL/dz_1 on the fly
                 self._k("dw_bwd1", "msl_dwconv_s2_bwd_bnreduce_bww_bf16", ptr(pl.g_z[1]), ptr(feats[1].conv1.weight), ptr(pl.y[0]),
@@ -893,7 +920,7 @@ class Engine:
             out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
             self._k(f"pw_bww{i}", "msl_pwconv_bwd_weight_slabs_bf16", ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]),
                     ptr(pl.bn_z[i][1]), ptr(out), N, sp["cin"], sp["cout"], S, sX)
-            if not fused_stem:  # (its partials came with the fused pass: pl.partials_wf)
+            if not fused_stem and not link_bww:  # (its partials came with the fused pass: pl.partials_wf / the link wrote dW)
                 self._k(f"dw_bww{i}", "msl_dwconv_bwd_weight_bf16", ptr(pl.g_z[i]), ptr(pl.y[i - 1]), ptr(pl.bn_y[i - 1][0]),
                         ptr(pl.bn_y[i - 1][1]), ptr(pl.dw_part[i]), N, sp["cin"], pd, ph, pw, s, sX)
             report(i, join_heads=True)  # (odd blocks put their weight gradients on the heads stream)

@@ -475,6 +475,41 @@ def test_stem_bwd_weight_bnapply_bf16(cin, dims):
     close(dw, refdw, 2e-4, 1e-4 * max(1.0, float(refdw.abs().max())), "stem dW from bf16 g / y with fused BN apply")
 
 
+@pytest.mark.parametrize("n,c,dims,stride,acc", [(4, 64, (4, 4, 4), 1, 1), (4, 32, (8, 8, 8), 2, 0), (4, 32, (8, 8, 8), 1, 1),
+                                                 (4, 16, (16, 16, 16), 2, 1), (4, 16, (16, 16, 16), 1, 0), (3, 8, (4, 8, 16), 1, 1)])
+def test_block_bwd_channel_link_bf16(n, c, dims, stride, acc):
+    """msl_block_bwd_channel_link_bf16 against the fp32 link on the same bf16-rounded operands: the two differ only by the
+    storage roundings (dL/dz, the intermediate dL/d relu(bn2(y)), dL/dy: half a bf16 ulp each); the BatchNorm / tap sums are
+    fp32 / fp64 on both sides."""
+    D, H, W = dims
+    OD, OH, OW = [(d - 1) // stride + 1 for d in dims]
+    g = bfr(rnd(n, c, OD, OH, OW, seed=1))
+    z = bfr(rnd(n, c, OD, OH, OW, seed=2))
+    y = bfr(rnd(n, c, D, H, W, seed=3))
+    hs = bfr(rnd(n, c, D, H, W, seed=4))
+    w = rnd(c, 27, seed=5, scale=0.3)
+
+    def vec(x, seed):
+        mean, var = x.mean(dim=(0, 2, 3, 4)), x.var(dim=(0, 2, 3, 4), unbiased=False)
+        inv = 1.0 / torch.sqrt(var + 1e-5)
+        gam = torch.rand(c, generator=torch.Generator().manual_seed(seed)) + 0.5
+        bet = rnd(c, seed=seed + 1, scale=0.3)
+        return torch.stack([gam * inv, bet - mean * gam * inv, mean, inv])
+    vz, vy = vec(z, 10), vec(y, 20)
+    ref = dict(gz=K(g), gy=K(hs), o=[K(torch.zeros(c)) for _ in range(4)], dw=K(torch.zeros(c, 27)))
+    _lib.call("msl_block_bwd_channel_link", ptr(ref["gz"]), ptr(K(z)), ptr(K(vz)), ptr(K(w)), ptr(K(y)), ptr(K(vy)), ptr(ref["gy"]),
+              *[ptr(t) for t in ref["o"]], ptr(ref["dw"]), n, c, D, H, W, stride, acc, st())
+    got = dict(gz=K(g.bfloat16()), gy=K(hs.bfloat16()), o=[K(torch.zeros(c)) for _ in range(4)], dw=K(torch.zeros(c, 27)))
+    _lib.call("msl_block_bwd_channel_link_bf16", ptr(got["gz"]), ptr(K(z.bfloat16())), ptr(K(vz)), ptr(K(w)), ptr(K(y.bfloat16())),
+              ptr(K(vy)), ptr(got["gy"]), *[ptr(t) for t in got["o"]], ptr(got["dw"]), n, c, D, H, W, stride, acc, st())
+    for k in ("gz", "gy"):
+        r = ref[k].float().cpu()
+        close(got[k].float(), r, 1.0 / 128, 1e-2 * float(r.abs().max()), k)  # one bf16 rounding of the output (+ of dz for gy)
+    for a, b, what in zip(got["o"], ref["o"], ("dgamma1", "dbeta1", "dgamma2", "dbeta2")):
+        close(a, b, 2e-2, 2e-2 * float(b.abs().max()), what)
+    close(got["dw"], ref["dw"], 2e-2, 2e-2 * float(ref["dw"].abs().max()), "depthwise weight gradient")
+
+
 def _models(size, seed=1234):
     from mslesions3d_amd.ssd3d import LSSD3D
     from oracle.network import OracleSSD3D
