@@ -302,6 +302,11 @@ int msl_multibox_match(const float* gt_boxes, const long long* gt_labels, const 
                        const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
                        int* obj, int* prior_for_obj, long long* true_classes, float* true_locs, long long* matched,
                        void* stream);
+/* the same; additionally *npos = number of positive priors of the batch (ssd3d.py:890-893), for msl_multibox_loss_pack */
+int msl_multibox_match_count(const float* gt_boxes, const long long* gt_labels, const int* obj_off, int total_objects,
+                             const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
+                             int* obj, int* prior_for_obj, long long* true_classes, float* true_locs, long long* matched,
+                             int* npos, void* stream);
 size_t msl_multibox_loss_workspace_bytes(void);
 /* loss part (ssd3d.py:890-941): loss_out[0] = conf_loss, [1] = loc_loss, [2] = number of positives */
 int msl_multibox_loss_fwd(const float* locs, const float* scores, const long long* true_classes,
@@ -316,6 +321,18 @@ int msl_multibox_loss_bwd(const float* locs, const float* scores, const long lon
 int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long long* true_classes,
                               const float* true_locs, double* workspace, float* loss_out, const float* upstream,
                               float* dlocs, float* dscores, int* nan_flag, int N, int P, int ncls, void* stream);
+
+/* Training hot loop, ONE launch: the loss terms of ssd3d.py:890-941, their gradients (the number of positives comes from
+ * msl_multibox_match_count, so no thread waits for the loss sums) and the scatter of those gradients into the zero-haloed
+ * head-gradient images of msl_head_grad_pack (dO_pad / D / H / W / prior_off: host arrays of n <= 4 scales; rows
+ * a*6+q = box regressions of anchor a, 12 + a*ncls + c = class scores; padding rows are not written and must be zero).
+ * partials: 2 * msl_multibox_loss_pack_num_partials(N, P) doubles; a kind-4 entry of msl_grad_reduce_batch folds them into
+ * loss_out = [conf_loss, loc_loss, n_positives].  upstream / nan_flag as msl_multibox_loss_fwd_bwd. */
+int msl_multibox_loss_pack_num_partials(int N, int P);
+int msl_multibox_loss_pack(const float* locs, const float* scores, const long long* true_classes, const float* true_locs,
+                           const int* npos, const float* upstream, double* partials, int* nan_flag, float* const* dO_pad,
+                           const int* D, const int* H, const int* W, const int* prior_off, int n, int N, int P, int ncls,
+                           void* stream);
 
 /* Optional loss variants the reference keeps as commented code (ssd3d.py:758-760 loss choices, :926-932 hard-negative
  * mining); flags: 1 = hard-negative mining (keep the neg_pos_ratio * n_positives largest negative losses per image),
@@ -353,7 +370,9 @@ int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream);
  * listed ones into the flat gradient arena in a fixed order.  The table is built on the host with _table_set (which
  * returns the number of workgroups of the entry; first_block = running sum) and uploaded by the caller.
  * kind 0: fp32 slabs [nslabs][stride] -> dst[i];  1: fp64 partials [count][nslabs] -> dst[i];  2: stem slabs, padded
- * [32][32*p1] image -> dst[co*p0 + k];  3: head slabs -> dst = dloc_w, dst2 = dcl_w (p0 = C, p1 = MT, p2 = 12 + 2*ncls). */
+ * [32][32*p1] image -> dst[co*p0 + k];  3: head slabs -> dst = dloc_w, dst2 = dcl_w (p0 = C, p1 = MT, p2 = 12 + 2*ncls);
+ * 4: the loss partials of msl_multibox_loss_pack (src fp64 [nslabs][2], dst2 = its int positives counter, count = 1)
+ * -> dst = loss_out [conf_loss, loc_loss, n_positives]. */
 size_t msl_grad_reduce_entry_bytes(void);
 int msl_grad_reduce_table_set(void* host_table, int index, int first_block, int kind, const void* src, float* dst,
                               float* dst2, int nslabs, int count, long long stride, int p0, int p1, int p2);

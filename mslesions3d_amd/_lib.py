@@ -113,6 +113,9 @@ _SIGNATURES = {
     "msl_box_transform": (_I, [_P, _P, _P, _I, _I, _P]),
     "msl_iou_matrix": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "msl_multibox_match": (_I, [_P, _P, _P, _I, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "msl_multibox_match_count": (_I, [_P, _P, _P, _I, _P, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "msl_multibox_loss_pack_num_partials": (_I, [_I, _I]),
+    "msl_multibox_loss_pack": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_multibox_loss_workspace_bytes": (_Z, []),
     "msl_multibox_loss_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_multibox_loss_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),

@@ -133,8 +133,9 @@ __global__ __launch_bounds__(256) void match_prior_best_kernel(const float* __re
                                                                const int* __restrict__ obj_off,
                                                                const float* __restrict__ priors_c,
                                                                float* __restrict__ overlap, int* __restrict__ obj,
-                                                               int P) {
+                                                               int P, int* __restrict__ npos) {
   const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (npos && n == 0 && p == 0) *npos = 0;  // the positives counter of match_encode_kernel (three launches later)
   if (p >= P) return;
   const int o0 = obj_off[n], o1 = obj_off[n + 1];
   const Box pb = c_to_xyz(load_box(priors_c + (size_t)p * 6));
@@ -226,8 +227,10 @@ __global__ __launch_bounds__(256) void match_encode_kernel(const float* __restri
                                                            const int* __restrict__ obj, float thr_lo, float thr_hi,
                                                            int soft, long long* __restrict__ true_classes,
                                                            float* __restrict__ true_locs,
-                                                           long long* __restrict__ matched, int P) {
+                                                           long long* __restrict__ matched, int P, int* __restrict__ npos,
+                                                           int npos_reset) {
   const int n = blockIdx.y, p = blockIdx.x * 256 + threadIdx.x;
+  if (npos && npos_reset && n == 0 && p == 0) *npos = 0;  // (a batch without objects: nobody adds, nobody zeroed it before)
   if (p >= P) return;
   const size_t idx = (size_t)n * P + p;
   const int o0 = obj_off[n], o1 = obj_off[n + 1];
@@ -245,6 +248,10 @@ __global__ __launch_bounds__(256) void match_encode_kernel(const float* __restri
   else if (soft && ov < thr_hi) lab = -1;
   true_classes[idx] = lab;
   if (matched) matched[idx] = o;
+  if (npos) {  // number of positive priors of the batch (ssd3d.py:890-893 n_positives.sum()): an exact integer count
+    const unsigned long long m = __ballot(lab > 0);
+    if (m && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(npos, __popcll(m));
+  }
   const Box t = encode_box(xyz_to_c(load_box(gt_boxes + (size_t)(o0 + o) * 6)), load_box(priors_c + (size_t)p * 6));
 #pragma unroll
   for (int q = 0; q < 6; ++q) true_locs[idx * 6 + q] = t.v[q];
@@ -381,6 +388,89 @@ __global__ __launch_bounds__(256) void multibox_loss_bwd_kernel(const float* __r
       g = d > 0.f ? gl : (d < 0.f ? -gl : 0.f);
     }
     dlocs[(size_t)i * 6 + q] = g;
+  }
+}
+
+// Loss of the training hot loop in ONE launch (ssd3d.py:890-941 + its autograd + the scatter of the head gradients): with
+// the number of positives known from the matching (msl_multibox_match_count) the per-prior gradients do not have to wait
+// for the loss sums, so a thread computes the cross entropy / L1 terms of its prior, their gradients
+//     dL/dscores = upstream[0] / n_pos * (softmax - onehot)   (ignored priors 0),   dL/dlocs = upstream[1] / (6 n_pos) * sign
+// and writes them straight into the zero-haloed (N, 16*MT, D+2, H+2, W+2) gradient images the head convolutions' backward
+// reads (row a*6 + q for the box regressions of anchor a, 12 + a*ncls + c for its class scores): no (N,P,.) gradient tensors,
+// no pack launch.  The (sum ce, sum l1) partials of the workgroups are folded into loss_out by the step's batched gradient
+// reduction (optim.hip kind 4) - nothing on the dependency chain waits for the loss VALUE.
+struct LossPackDst {
+  float* dO[4];
+  int D[4], H[4], W[4], prior_off[4];
+};
+__global__ __launch_bounds__(256) void multibox_loss_pack_kernel(
+    const float* __restrict__ locs, const float* __restrict__ scores, const long long* __restrict__ true_classes,
+    const float* __restrict__ true_locs, const int* __restrict__ npos, const float* __restrict__ upstream,
+    double* __restrict__ partials, int* __restrict__ nan_flag, LossPackDst dst, int nscales, int N, int P, int ncls, int CO) {
+  __shared__ double scratch[8];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float npf = (float)*npos;
+  const float gc = upstream[0] / npf, gl = upstream[1] / (npf * 6.0f);
+  double ce = 0.0, l1 = 0.0;
+  bool bad_loc = false, bad_score = false;
+  if (i < N * P) {
+    const int n = i / P, p = i - n * P;
+    const long long tc = true_classes[i];
+    const float* x = scores + (size_t)i * ncls;
+    float xs[MAXC], gs[MAXC], lq[6], gq[6];
+    for (int c = 0; c < ncls; ++c) {
+      xs[c] = x[c];
+      bad_score |= isnan(xs[c]);
+      gs[c] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      lq[q] = locs[(size_t)i * 6 + q];
+      bad_loc |= isnan(lq[q]);
+      gq[q] = 0.f;
+    }
+    if (tc >= 0) {
+      float m = xs[0];
+      for (int c = 1; c < ncls; ++c) m = fmaxf(m, xs[c]);
+      float se = 0.f;
+      for (int c = 0; c < ncls; ++c) se += expf(xs[c] - m);
+      ce = (double)((m + logf(se)) - xs[tc]);
+      for (int c = 0; c < ncls; ++c) gs[c] = gc * (expf(xs[c] - m) / se - (c == (int)tc ? 1.0f : 0.0f));
+    }
+    if (tc > 0) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        const float d = lq[q] - true_locs[(size_t)i * 6 + q];
+        a += fabsf(d);
+        gq[q] = d > 0.f ? gl : (d < 0.f ? -gl : 0.f);
+      }
+      l1 = (double)a;
+    }
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < 4; ++j)
+      if (j < nscales && p >= dst.prior_off[j]) k = j;
+    const int local = p - dst.prior_off[k], pos = local >> 1, a = local & 1;  // two anchors per location (ssd3d.py:213)
+    const int W = dst.W[k], H = dst.H[k], D = dst.D[k];
+    const int w = pos % W, h = (pos / W) % H, d = pos / (W * H);
+    const int Hp = H + 2, Wp = W + 2;
+    const size_t volp = (size_t)(D + 2) * Hp * Wp;
+    float* base = dst.dO[k] + (size_t)n * CO * volp + ((size_t)(d + 1) * Hp + h + 1) * Wp + w + 1;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) base[(size_t)(a * 6 + q) * volp] = gq[q];
+    for (int c = 0; c < ncls; ++c) base[(size_t)(12 + a * ncls + c) * volp] = gs[c];
+  }
+  if (nan_flag) {  // the NaN guards of ssd3d.py:258-261 for free: this kernel reads every loc and score anyway
+    if (__any(bad_loc) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 1);
+    if (__any(bad_score) && (threadIdx.x & 63) == 0) atomicOr(nan_flag, 2);
+  }
+  const double t0 = msl::block_sum(ce, scratch);
+  __syncthreads();
+  const double t1 = msl::block_sum(l1, scratch);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 2 + 0] = t0;
+    partials[blockIdx.x * 2 + 1] = t1;
   }
 }
 
@@ -657,15 +747,15 @@ int msl_iou_matrix(const float* set1, const float* set2, float* out, int n1, int
 
 // gt_boxes (T,6) corner form, gt_labels (T,), obj_off (N+1,) prefix offsets into them, all on device.
 // scratch: overlap (N,P) f32, obj (N,P) i32, prior_for_obj (T,) i32.  soft != 0 -> two-threshold band.
-int msl_multibox_match(const float* gt_boxes, const long long* gt_labels, const int* obj_off, int total_objects,
-                       const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
-                       int* obj, int* prior_for_obj, long long* true_classes, float* true_locs,
-                       long long* matched, void* stream) {
+static int match_impl(const float* gt_boxes, const long long* gt_labels, const int* obj_off, int total_objects,
+                      const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
+                      int* obj, int* prior_for_obj, long long* true_classes, float* true_locs,
+                      long long* matched, int* npos, void* stream) {
   if (N <= 0 || P <= 0 || total_objects < 0) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   dim3 gp(msl::cdiv(P, 256), N);
   if (total_objects > 0) {
-    hipLaunchKernelGGL(match_prior_best_kernel, gp, dim3(256), 0, st, gt_boxes, obj_off, priors_c, overlap, obj, P);
+    hipLaunchKernelGGL(match_prior_best_kernel, gp, dim3(256), 0, st, gt_boxes, obj_off, priors_c, overlap, obj, P, npos);
     MSL_LAUNCH_CHECK();
     hipLaunchKernelGGL(match_object_best_kernel, dim3(total_objects), dim3(MOB_T), 0, st, gt_boxes, priors_c,
                        prior_for_obj, P);
@@ -674,9 +764,27 @@ int msl_multibox_match(const float* gt_boxes, const long long* gt_labels, const 
     MSL_LAUNCH_CHECK();
   }
   hipLaunchKernelGGL(match_encode_kernel, gp, dim3(256), 0, st, gt_boxes, gt_labels, obj_off, priors_c, overlap, obj,
-                     thr_lo, thr_hi, soft, true_classes, true_locs, matched, P);
+                     thr_lo, thr_hi, soft, true_classes, true_locs, matched, P, npos, total_objects > 0 ? 0 : 1);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
+}
+
+int msl_multibox_match(const float* gt_boxes, const long long* gt_labels, const int* obj_off, int total_objects,
+                       const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
+                       int* obj, int* prior_for_obj, long long* true_classes, float* true_locs,
+                       long long* matched, void* stream) {
+  return match_impl(gt_boxes, gt_labels, obj_off, total_objects, priors_c, N, P, thr_lo, thr_hi, soft, overlap, obj,
+                    prior_for_obj, true_classes, true_locs, matched, nullptr, stream);
+}
+
+// the same, and *npos = number of positive priors of the batch (for msl_multibox_loss_pack)
+int msl_multibox_match_count(const float* gt_boxes, const long long* gt_labels, const int* obj_off, int total_objects,
+                             const float* priors_c, int N, int P, float thr_lo, float thr_hi, int soft, float* overlap,
+                             int* obj, int* prior_for_obj, long long* true_classes, float* true_locs,
+                             long long* matched, int* npos, void* stream) {
+  if (!npos) return MSL_ERR_ARG;
+  return match_impl(gt_boxes, gt_labels, obj_off, total_objects, priors_c, N, P, thr_lo, thr_hi, soft, overlap, obj,
+                    prior_for_obj, true_classes, true_locs, matched, npos, stream);
 }
 
 size_t msl_multibox_loss_workspace_bytes(void) { return (size_t)LOSS_BLOCKS * 3 * sizeof(double); }
@@ -719,6 +827,32 @@ int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long
   MSL_LAUNCH_CHECK();
   hipLaunchKernelGGL(multibox_loss_bwd_kernel<true>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores,
                      true_classes, true_locs, loss_out, workspace, LOSS_BLOCKS, upstream, dlocs, dscores, N * P, ncls);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// Loss + loss gradient + head-gradient images in one launch (training hot loop; see multibox_loss_pack_kernel).  npos: the
+// counter msl_multibox_match_count filled; partials: 2 * msl_multibox_loss_pack_num_partials(N, P) doubles, folded into
+// loss_out = [conf, loc, n_positives] by a kind-4 entry of msl_grad_reduce_batch; dO_pad / D / H / W / prior_off: host arrays of
+// n <= 4 scales (the zero-haloed gradient images of msl_head_grad_pack, whose padding rows must be zero and stay untouched).
+int msl_multibox_loss_pack_num_partials(int N, int P) { return msl::cdiv(N * P, 256); }
+
+int msl_multibox_loss_pack(const float* locs, const float* scores, const long long* true_classes, const float* true_locs,
+                           const int* npos, const float* upstream, double* partials, int* nan_flag, float* const* dO_pad,
+                           const int* D, const int* H, const int* W, const int* prior_off, int n, int N, int P, int ncls,
+                           void* stream) {
+  if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC || n <= 0 || n > 4 || !npos || !upstream || !partials) return MSL_ERR_ARG;
+  LossPackDst dst;
+  for (int k = 0; k < n; ++k) {
+    dst.dO[k] = dO_pad[k];
+    dst.D[k] = D[k];
+    dst.H[k] = H[k];
+    dst.W[k] = W[k];
+    dst.prior_off[k] = prior_off[k];
+  }
+  const int CO = 16 * ((12 + 2 * ncls + 15) / 16);
+  hipLaunchKernelGGL(multibox_loss_pack_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream, locs, scores,
+                     true_classes, true_locs, npos, upstream, partials, nan_flag, dst, n, N, P, ncls, CO);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

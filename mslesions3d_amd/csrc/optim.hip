@@ -45,7 +45,7 @@ struct GradReduceEntry {   // 64 bytes, filled on the host by msl_grad_reduce_ta
   int kind, nslabs, count, first_block;
   int p0, p1, p2, pad;
 };
-enum { GR_SLAB_F32 = 0, GR_ELEM_F64 = 1, GR_STEM_F32 = 2, GR_HEAD_F32 = 3 };
+enum { GR_SLAB_F32 = 0, GR_ELEM_F64 = 1, GR_STEM_F32 = 2, GR_HEAD_F32 = 3, GR_LOSS = 4 };
 
 // Output address of element i of a slab-major entry (nullptr: padding, nothing to store).
 __device__ __forceinline__ float* grad_reduce_dst(const GradReduceEntry& en, int i) {
@@ -81,6 +81,27 @@ __global__ __launch_bounds__(256) void grad_reduce_batch_kernel(const GradReduce
   const GradReduceEntry en = table[e];
   const int blk = blockIdx.x - en.first_block;
   const int li = threadIdx.x & 31, g = threadIdx.x >> 5;
+  if (en.kind == GR_LOSS) {
+    // loss values of msl_multibox_loss_pack: src = fp64 [nslabs][2] (sum ce, sum l1) per workgroup, dst2 = the positives counter
+    // (int) -> dst = [conf, loc, n_positives] (ssd3d.py:896, :933); one wave, lanes strided over the partials, fixed order
+    if (threadIdx.x < 64) {
+      const double* src = (const double*)en.src;
+      double ce = 0.0, l1 = 0.0;
+      for (int k = threadIdx.x; k < en.nslabs; k += 64) {
+        ce += src[2 * k];
+        l1 += src[2 * k + 1];
+      }
+      ce = msl::wave_sum(ce);
+      l1 = msl::wave_sum(l1);
+      if (threadIdx.x == 0) {
+        const float f = (float)*reinterpret_cast<const int*>(en.dst2);
+        en.dst[0] = (float)ce / f;
+        en.dst[1] = (float)l1 / (f * 6.0f);
+        en.dst[2] = f;
+      }
+    }
+    return;
+  }
   if (en.kind == GR_ELEM_F64) {
     // partials of one element are contiguous: 32 lanes walk them (coalesced), 8 elements per pass, 4 passes
     const double* src = (const double*)en.src;
@@ -198,11 +219,14 @@ size_t msl_grad_reduce_entry_bytes(void) { return sizeof(GradReduceEntry); }
 //   kind 2  fp32 slabs of the padded stem image [32][32*p1]  -> dst[co*p0 + k], k < p0       (stem; count = 1024 * p1)
 //   kind 3  fp32 head slabs (msl_head_conv_bwd_weight)       -> dst = dloc_w, dst2 = dcl_w   (p0 = C, p1 = MT, p2 = 12+2*ncls;
 //                                                                                            count = stride = (C/16)*27*MT*256)
+//   kind 4  loss partials of msl_multibox_loss_pack: src fp64 [nslabs][2], dst2 = its positives counter (int*), count = 1
+//                                                            -> dst = loss_out [conf, loc, n_positives]
 int msl_grad_reduce_table_set(void* host_table, int index, int first_block, int kind, const void* src, float* dst,
                               float* dst2, int nslabs, int count, long long stride, int p0, int p1, int p2) {
-  if (!host_table || index < 0 || kind < 0 || kind > 3 || !src || !dst || nslabs <= 0 || count <= 0) return MSL_ERR_ARG;
+  if (!host_table || index < 0 || kind < 0 || kind > 4 || !src || !dst || nslabs <= 0 || count <= 0) return MSL_ERR_ARG;
   GradReduceEntry e{src, dst, dst2, stride, kind, nslabs, count, first_block, p0, p1, p2, 0};
   ((GradReduceEntry*)host_table)[index] = e;
+  if (kind == GR_LOSS) return dst2 ? 1 : MSL_ERR_ARG;
   if (grad_reduce_few(kind, nslabs, count, stride) && ((uintptr_t)src % 16 == 0) && (kind != GR_SLAB_F32 || (uintptr_t)dst % 16 == 0))
     return msl::cdiv(count, 1024);
   ((GradReduceEntry*)host_table)[index].pad = 1;  // force the many-slab form (unaligned pointers)

@@ -827,7 +827,9 @@ class Engine:
         else:
             stH = stW = st
         N, ncls = pl.N, m.n_classes
-        dlocs, dscores = dlocs.contiguous(), dscores.contiguous()
+        prepacked = dlocs is None  # the loss kernel wrote the head-gradient images itself (MultiBoxLoss._run_loss_pack)
+        if not prepacked:
+            dlocs, dscores = dlocs.contiguous(), dscores.contiguous()
         last = len(specs) - 1
         L = _lib.load()
         pre_np, linked = None, False
@@ -853,8 +855,8 @@ class Engine:
                     ptr(pl.head_ws[f]), N, C, D, H, W, ncls, s_weight)
 
         side_feats = [f for f in pl.feat_ids if f != last] if ms else []
-        packed = bool(side_feats) and self.batch_head_gpack
-        if packed:
+        packed = prepacked or (bool(side_feats) and self.batch_head_gpack)
+        if packed and not prepacked:
             self._head_gpack_batch(pl, dlocs, dscores, st)
         if side_feats:
             self._fork(pl, "bwd_loss_ready", st, stH)
@@ -1172,8 +1174,10 @@ class Engine:
         N = pl.N
         specs = self.layer_specs
         feats = m.base.features
-        dlocs = dlocs.contiguous()
-        dscores = dscores.contiguous()
+        prepacked = dlocs is None  # the loss kernel wrote the head-gradient images itself (MultiBoxLoss._run_loss_pack)
+        if not prepacked:
+            dlocs = dlocs.contiguous()
+            dscores = dscores.contiguous()
         wanted = getattr(on_bucket_ready, "stages", None)
         # data parallel: the partial sums of a gradient bucket are folded when the bucket's last stage has been enqueued
         # (stage -> parameter names); single process: one reduction at the very end
@@ -1185,8 +1189,8 @@ class Engine:
         # the chain reaches their feature map, so they run on the heads stream beside blocks 7..4
         last = len(specs) - 1
         side_feats = [f for f in pl.feat_ids if f != last] if ms else []
-        packed = bool(side_feats) and self.batch_head_gpack
-        if packed:
+        packed = prepacked or (bool(side_feats) and self.batch_head_gpack)
+        if packed and not prepacked:
             self._head_gpack_batch(pl, dlocs, dscores, st)
         if side_feats:
             self._fork(pl, "bwd_loss_ready", st, stH)
@@ -1386,7 +1390,9 @@ class Engine:
         slabs) of the parameters in ``names`` (None: all) into the gradient arena (table built once per plan and key)."""
         import ctypes
         L = _lib.load()
-        ent = pl.grad_tables.get(key)
+        fold = getattr(pl, "loss_fold", None)
+        tkey = (key, None if fold is None else ptr(fold[0]))
+        ent = pl.grad_tables.get(tkey)
         if ent is None:
             gv = self.arena.grad_views
             specs, m = self.layer_specs, self.model
@@ -1421,6 +1427,10 @@ class Engine:
                 K = specs[0]["cin"] * 27
                 nt = (K + 31) // 32
                 rows.append((2, pl.ws_stem, gv["base.features.0.0.weight"], None, pl.stem_nslabs, 1024 * nt, 1024 * nt, K, nt, 0))
+            fold = getattr(pl, "loss_fold", None)
+            if fold is not None and key in ("all", 0):  # the loss values of MultiBoxLoss._run_loss_pack ride along (kind 4)
+                parts, nparts, loss_out, npos = fold
+                rows.append((4, parts, loss_out, npos, nparts, 1, 0, 0, 0, 0))
             esz = L.msl_grad_reduce_entry_bytes()
             host = (ctypes.c_ubyte * (esz * max(len(rows), 1)))()
             first = 0
@@ -1431,7 +1441,7 @@ class Engine:
                     raise _lib.HipKernelError(f"msl_grad_reduce_table_set failed for entry {k} (kind {kind})")
                 first += nb
             table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.arena.grad.device) if rows else None
-            ent = pl.grad_tables[key] = (table, len(rows), first)
+            ent = pl.grad_tables[tkey] = (table, len(rows), first)
         table, n, blocks = ent
         if n:
             self._k(f"grad_reduce:{key}", "msl_grad_reduce_batch", ptr(table), n, blocks, st)

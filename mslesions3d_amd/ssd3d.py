@@ -737,7 +737,10 @@ class MultiBoxLoss(nn.Module):
                       ws=torch.zeros(L.msl_multibox_loss_workspace_bytes() // 8, dtype=torch.float64, device=dev),
                       loss_out=torch.zeros(3, dtype=f32, device=dev), upstream=torch.ones(2, dtype=f32, device=dev),
                       dlocs=torch.zeros((N, P, 6), dtype=f32, device=dev),
-                      dscores=torch.zeros((N, P, ncls), dtype=f32, device=dev))
+                      dscores=torch.zeros((N, P, ncls), dtype=f32, device=dev),
+                      # fused hot-loop form (msl_multibox_loss_pack): positives counter of the matching + loss partials
+                      npos=torch.zeros(1, dtype=i32, device=dev),
+                      pack_parts=torch.zeros(2 * L.msl_multibox_loss_pack_num_partials(N, P), dtype=torch.float64, device=dev))
             self._states[key] = st
         if st["prior_for_obj"].numel() < total_objects:
             st["prior_for_obj"] = torch.zeros(2 * total_objects, dtype=torch.int32, device=dev)
@@ -771,13 +774,39 @@ class MultiBoxLoss(nn.Module):
             return float(self.threshold), 0.0, 0
         return float(self.threshold[0]), float(self.threshold[1]), 1
 
-    def _run_match(self, st, N, gt_boxes, gt_labels, obj_off, T, stream=None):
-        """Matching + target encoding only (depends on the ground truth and the priors, not on the network)."""
+    def _run_match(self, st, N, gt_boxes, gt_labels, obj_off, T, stream=None, count=False):
+        """Matching + target encoding only (depends on the ground truth and the priors, not on the network).  ``count``: also
+        leave the number of positive priors in ``st["npos"]`` (what ``_run_loss_pack`` divides by)."""
         P = self.priors_cxcycz.size(0)
         lo, hi, soft = self._thresholds()
-        _lib.call("msl_multibox_match", ptr(gt_boxes), ptr(gt_labels), ptr(obj_off), T, ptr(self.priors_cxcycz), N, P, lo,
-                  hi, soft, ptr(st["overlap"]), ptr(st["obj"]), ptr(st["prior_for_obj"]), ptr(st["true_classes"]),
-                  ptr(st["true_locs"]), ptr(st["matched"]), _stream() if stream is None else stream)
+        args = [ptr(gt_boxes), ptr(gt_labels), ptr(obj_off), T, ptr(self.priors_cxcycz), N, P, lo, hi, soft, ptr(st["overlap"]),
+                ptr(st["obj"]), ptr(st["prior_for_obj"]), ptr(st["true_classes"]), ptr(st["true_locs"]), ptr(st["matched"])]
+        if count:
+            _lib.call("msl_multibox_match_count", *args, ptr(st["npos"]), _stream() if stream is None else stream)
+        else:
+            _lib.call("msl_multibox_match", *args, _stream() if stream is None else stream)
+
+    def can_pack(self, n_scales):
+        """Is the one-launch loss + gradient + head-gradient-image form available (the live loss, at most four scales)?"""
+        return not self.variant_flags and n_scales <= 4
+
+    def _run_loss_pack(self, st, locs, scores, upstream, nan_flag, dO, dims, prior_off):
+        """Loss terms, their gradients and the zero-haloed head-gradient images in one launch (training hot loop; the targets
+        and the positives counter are in ``st``: ``_run_match(count=True)``).  ``dO`` / ``dims`` / ``prior_off``: per scale.  The
+        loss VALUES reach ``st["loss_out"]`` with the step's batched gradient reduction (Engine._grad_reduce, kind 4)."""
+        import ctypes
+        N, P, ncls = locs.shape[0], locs.shape[1], scores.shape[2]
+        assert P == self.priors_cxcycz.size(0) == scores.size(1)  # ssd3d.py:845
+        n = len(dO)
+        key = tuple(ptr(t) for t in dO) + tuple(prior_off)
+        if st.get("pack_key") != key:
+            I = ctypes.c_int * n
+            st["pack_args"] = ((ctypes.c_void_p * n)(*[ptr(t) for t in dO]),) + tuple(I(*[d[a] for d in dims]) for a in range(3)) + (
+                I(*prior_off),)
+            st["pack_key"] = key
+        a = st["pack_args"]  # host arrays: kept alive by the state (a recorded launch program points at them)
+        _lib.call("msl_multibox_loss_pack", ptr(locs), ptr(scores), ptr(st["true_classes"]), ptr(st["true_locs"]), ptr(st["npos"]),
+                  ptr(upstream), ptr(st["pack_parts"]), ptr(nan_flag), *[ctypes.addressof(x) for x in a], n, N, P, ncls, _stream())
 
     def _run_forward(self, st, locs, scores, gt_boxes, gt_labels, obj_off, T, with_backward_upstream=None,
                      matched=False, nan_flag=None):

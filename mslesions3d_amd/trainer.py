@@ -72,7 +72,7 @@ class FusedTrainer:
 
             def run_match():
                 eng._fork(pl0, "match_start", main, sM)
-                lf._run_match(st, N, gt_boxes, gt_labels, obj_off, total_objects, stream=sM)
+                lf._run_match(st, N, gt_boxes, gt_labels, obj_off, total_objects, stream=sM, count=True)
             if k > 0:
                 after = {k: run_match}
             else:
@@ -84,9 +84,18 @@ class FusedTrainer:
         if "upstream_alpha" not in st or st["upstream_alpha_value"] != float(lf.alpha):
             st["upstream_alpha"] = torch.tensor([1.0, float(lf.alpha)], dtype=torch.float32, device=dev)  # loss = conf + alpha*loc
             st["upstream_alpha_value"] = float(lf.alpha)
-        lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects,
-                        with_backward_upstream=st["upstream_alpha"], matched=eng.multi_stream, nan_flag=pl.nan_flag)
-        eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red)
+        if eng.multi_stream and lf.can_pack(len(pl.feat_ids)):
+            # loss terms + their gradients + the head-gradient images in ONE launch (the matching left the number of positives);
+            # the loss values are folded by the batched gradient reduction at the end of the step
+            lf._run_loss_pack(st, locs, scores, st["upstream_alpha"], pl.nan_flag, [pl.dO[f] for f in pl.feat_ids],
+                              [pl.dims[f] for f in pl.feat_ids], [pl.prior_off[f] for f in pl.feat_ids])
+            pl.loss_fold = (st["pack_parts"], st["pack_parts"].numel() // 2, st["loss_out"], st["npos"])
+            eng.backward(pl, None, None, on_bucket_ready=red)
+        else:
+            pl.loss_fold = None
+            lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects,
+                            with_backward_upstream=st["upstream_alpha"], matched=eng.multi_stream, nan_flag=pl.nan_flag)
+            eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red)
         scale = red.finish()
         if red.active:
             _lib.record_hook(red.finish, tag="hook:finish")

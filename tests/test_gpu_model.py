@@ -1014,3 +1014,62 @@ def test_five_prediction_scales_golden():
     np.testing.assert_allclose(out["loc"], float(g["loc"]), rtol=RTOL)
     out2 = FusedTrainer(m).step(x, boxes, labels)
     assert np.isfinite(out2["loss"])
+
+
+# ------------------------------------------------------------------------------------------------- one-launch loss
+@pytest.mark.parametrize("ncls,empty_image", [(2, False), (3, False), (2, True)])
+def test_loss_pack_equals_the_two_launch_form(ncls, empty_image):
+    """msl_multibox_match_count + msl_multibox_loss_pack (the training hot loop: loss terms, gradients and head-gradient images
+    in one launch, loss values folded by a kind-4 entry of the batched gradient reduction) against msl_multibox_loss_fwd_bwd +
+    msl_head_grad_pack_batch: identical gradient images, losses within 1e-6 (another summation order), same positives count."""
+    import ctypes
+    from mslesions3d_amd import _lib
+    from mslesions3d_amd._lib import ptr
+    from mslesions3d_amd.ssd3d import LSSD3D, MultiBoxLoss
+    size, n = (64, 64, 64), 3
+    m = LSSD3D(n_classes=ncls, input_channels=1, input_size=size, threshold=[0.1, 0.2]).to(DEV)
+    lf, P = m.loss_fn, m.priors_cxcycz.shape[0]
+    boxes, labels = cases.multiclass_gt(8, n, size, n_fg=ncls - 1)
+    if empty_image:
+        boxes[1], labels[1] = torch.zeros((0, 6)), torch.zeros((0,), dtype=torch.long)
+    gb, gl, off, T = MultiBoxLoss.pack_targets(boxes, labels, torch.device(DEV))
+    locs, scores = detinit.make_head_outputs(33, n, P, n_classes=ncls)
+    locs, scores = locs.to(DEV), scores.to(DEV)
+    st = lf._state(n, P, ncls, T, torch.device(DEV))
+    up = torch.tensor([1.0, 0.7], device=DEV)
+    dims = {3: (8, 8, 8), 5: (4, 4, 4), 7: (2, 2, 2)}
+    offs, o = {}, 0
+    for f, d in dims.items():
+        offs[f] = o
+        o += 2 * d[0] * d[1] * d[2]
+    assert o == P
+    CO = 16 * ((12 + 2 * ncls + 15) // 16)
+    mk = lambda: {f: torch.zeros((n, CO) + tuple(x + 2 for x in d), device=DEV) for f, d in dims.items()}
+    stream = torch.cuda.current_stream().cuda_stream
+    # reference: two loss launches + the pack launch
+    lf._run_match(st, n, gb, gl, off, T)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    lf._run_forward(st, locs, scores, gb, gl, off, T, with_backward_upstream=up, matched=True, nan_flag=flag)
+    ref_loss = st["loss_out"].clone()
+    ref_dO = mk()
+    for f, d in dims.items():
+        _lib.call("msl_head_grad_pack", ptr(st["dlocs"]), ptr(st["dscores"]), ptr(ref_dO[f]), n, *d, P, offs[f], ncls, stream)
+    # one launch
+    st["loss_out"].zero_()
+    lf._run_match(st, n, gb, gl, off, T, count=True)
+    got_dO = mk()
+    lf._run_loss_pack(st, locs, scores, up, flag, [got_dO[f] for f in dims], [dims[f] for f in dims], [offs[f] for f in dims])
+    L = _lib.load()
+    esz = L.msl_grad_reduce_entry_bytes()
+    host = (ctypes.c_ubyte * esz)()
+    nparts = st["pack_parts"].numel() // 2
+    assert L.msl_grad_reduce_table_set(ctypes.addressof(host), 0, 0, 4, ptr(st["pack_parts"]), ptr(st["loss_out"]), ptr(st["npos"]),
+                                       nparts, 1, 0, 0, 0, 0) == 1
+    table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(DEV)
+    _lib.call("msl_grad_reduce_batch", ptr(table), 1, 1, stream)
+    torch.cuda.synchronize()
+    assert int(st["npos"]) == int(ref_loss[2]) == int((st["true_classes"] > 0).sum())
+    np.testing.assert_allclose(st["loss_out"].cpu().numpy(), ref_loss.cpu().numpy(), rtol=1e-6)
+    for f in dims:
+        assert torch.equal(got_dO[f], ref_dO[f]), f"head-gradient image of scale {f}"
+    assert int(flag) == 0
