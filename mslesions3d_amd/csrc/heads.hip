@@ -527,7 +527,7 @@ constexpr int HEAD_FWD_CH = 16;
 // form at 16^3 x 4, C = 128: 30.7 us = 11.5 MFMA + 10 B-operand reads + 6.5 A-operand reads + staging, back to back: with
 // one wave per SIMD nothing hides a wait.  More workgroups per CU did not help: they duplicate the staging.)
 constexpr int HEAD_FWD_NT = 512;
-template <int W, int MT>
+template <int W, int MT, int CH = HEAD_FWD_CH>
 __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* __restrict__ a_pad, const float* __restrict__ Wf,
                                                                    const float* __restrict__ loc_b, const float* __restrict__ cl_b,
                                                                    float* __restrict__ locs, float* __restrict__ scores,
@@ -535,13 +535,14 @@ __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* 
                                                                    int prior_off, int ncls, int co_total, int KSG) {
   typedef HeadGeo<W> G;
   constexpr int NT = HEAD_FWD_NT;
-  constexpr int SLAB = G::PD * G::PH * G::PW, CH = HEAD_FWD_CH, NCG = CH / 4;
+  constexpr int SLAB = G::PD * G::PH * G::PW, NCG = CH / 4;
   constexpr int NS = (CH * SLAB + NT - 1) / NT;        // slab floats per thread and chunk
   constexpr int AF4 = NCG * 27 * MT * 64 / 4;          // weight fragments of a chunk, in float4
   constexpr int NA = (AF4 + NT - 1) / NT;
   static_assert(NCG % 2 == 0, "two waves share a tile's channel groups");
-  __shared__ __align__(16) float slab[CH * G::CS];
-  __shared__ __align__(16) float afr[AF4 * 4];
+  extern __shared__ __align__(16) float head_fwd_dyn[];  // [CH * CS] input slab | [AF4 * 4] weight fragments
+  float* slab = head_fwd_dyn;
+  float* afr = head_fwd_dyn + CH * G::CS;
   const int n = blockIdx.y, ksg = blockIdx.z, b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
   const int tile = wv & 3, khalf = wv >> 2;
@@ -587,20 +588,28 @@ __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* 
       const int cgl = khalf * (NCG / 2) + cg2;
       const float* sp = slab + (cgl * 4 + q) * G::CS + ob;
       const float* fp = afr + (size_t)cgl * 27 * MT * 64 + lane;
+      // all operand reads of the channel group leave before its first MFMA (left to itself the compiler reads two operands,
+      // waits, issues two MFMAs).  Measured neutral with two waves per SIMD (27.3 -> 27.8 us at 16^3): the loop is bound by
+      // LDS bytes - two 256-byte operand reads per 32-cycle MFMA are half of the CU's LDS bandwidth - not by their latency
+      float bq[27], aq[27 * MT];
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int tap = kd * 9 + kh * 3 + kw;
-            const float bq = sp[(kd * G::PH + kh) * G::PW + kw];
+          for (int kw = 0; kw < 3; ++kw) bq[kd * 9 + kh * 3 + kw] = sp[(kd * G::PH + kh) * G::PW + kw];
 #pragma unroll
-            for (int m = 0; m < MT; ++m) {
-              if (tap & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[(tap * MT + m) * 64], bq, acc2[m], 0, 0, 0);
-              else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[(tap * MT + m) * 64], bq, acc[m], 0, 0, 0);
-            }
-          }
+      for (int t = 0; t < 27 * MT; ++t) aq[t] = fp[t * 64];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (tap & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap * MT + m], bq[tap], acc2[m], 0, 0, 0);
+          else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap * MT + m], bq[tap], acc[m], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
@@ -675,17 +684,22 @@ __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __r
     for (int cog = 0; cog < COG; ++cog) {
       const float* sp = slab + (cog * 4 + q) * G::CS + ob;
       const float* fp = afr + (size_t)cog * 27 * 64 + lane;
+      float bq[27], aq[27];  // all operand reads of the group first, then its MFMAs (see head_fwd_lds_kernel)
 #pragma unroll
       for (int kd = 0; kd < 3; ++kd)
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const int tap = kd * 9 + kh * 3 + kw;
-            const float bq = sp[((2 - kd) * G::PH + (2 - kh)) * G::PW + (2 - kw)];
-            if (tap & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[tap * 64], bq, acc2, 0, 0, 0);
-            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fp[tap * 64], bq, acc, 0, 0, 0);
-          }
+          for (int kw = 0; kw < 3; ++kw) bq[kd * 9 + kh * 3 + kw] = sp[((2 - kd) * G::PH + (2 - kh)) * G::PW + (2 - kw)];
+#pragma unroll
+      for (int t = 0; t < 27; ++t) aq[t] = fp[t * 64];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        if (tap & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap], bq[tap], acc2, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap], bq[tap], acc, 0, 0, 0);
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     acc += acc2;
 #pragma unroll
@@ -804,28 +818,35 @@ __global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restri
       if (b0 + u >= blk_hi) break;  // uniform
       const float* fslab = lds + u * (FSZ + DSZ);
       const float* dtile = fslab + FSZ;
+      // every operand read of the block first, then its 36-40 MFMAs (see head_fwd_lds_kernel: the compiler otherwise waits
+      // for each pair of operands right in front of their MFMAs)
+      float a[4][MT], bq[4][9];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         const int pb = wv * 16 + 4 * s + q;
         const float* sp = fslab + j * G::CSK + head_block_off<W>(pb);
-        float a[MT];
 #pragma unroll
-        for (int m = 0; m < MT; ++m) a[m] = dtile[(m * 16 + j) * DLD + pb];
+        for (int m = 0; m < MT; ++m) a[s][m] = dtile[(m * 16 + j) * DLD + pb];
 #pragma unroll
         for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-          for (int kw = 0; kw < 3; ++kw) {
-            const float bq = sp[kh * G::PW + kw];
+          for (int kw = 0; kw < 3; ++kw) bq[s][kh * 3 + kw] = sp[kh * G::PW + kw];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int m = 0; m < MT; ++m)
-              acc[(kh * 3 + kw) * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bq, acc[(kh * 3 + kw) * MT + m], 0, 0, 0);
-          }
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int m = 0; m < MT; ++m)
+            acc[t * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][m], bq[s][t], acc[t * MT + m], 0, 0, 0);
         if (do_bias) {
 #pragma unroll
           for (int m = 0; m < MT; ++m)
-            acc[9 * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], 1.0f, acc[9 * MT + m], 0, 0, 0);
+            acc[9 * MT + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s][m], 1.0f, acc[9 * MT + m], 0, 0, 0);
         }
       }
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
   // fixed-order reduction over the 4 waves
@@ -1080,8 +1101,12 @@ int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, c
   if (lw) {
     dim3 grid(S / 64, N, ksg);
 #define MSL_HF(W_, MT_)                                                                                              \
-  hipLaunchKernelGGL((head_fwd_lds_kernel<W_, MT_>), grid, dim3(HEAD_FWD_NT), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, \
-                     workspace, C, D, Ptot, prior_off, ncls, co_total, ksg)
+  do {                                                                                                               \
+    const size_t smem = ((size_t)HEAD_FWD_CH * HeadGeo<W_>::CS + (size_t)(HEAD_FWD_CH / 4) * 27 * MT_ * 64) * sizeof(float); \
+    hipLaunchKernelGGL((head_fwd_lds_kernel<W_, MT_>), grid, dim3(HEAD_FWD_NT), smem, st, a_pad, Wf, loc_b, cl_b, locs,  \
+                       scores, workspace, C, D, Ptot, prior_off, ncls, co_total, ksg);                                \
+  } while (0)
+    // (chunks of 32 channels - half the barriers, twice the MFMA time per prefetch - measured equal: 27.3 vs 28.0 us at 16^3)
     if (lw == 16) MSL_HF(16, 1); else if (lw == 8) MSL_HF(8, 1); else MSL_HF(4, 1);
 #undef MSL_HF
   } else {

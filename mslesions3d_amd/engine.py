@@ -518,9 +518,8 @@ class Engine:
                         ptr(blk.conv2.weight), ptr(pl.y[i]), ptr(pl.part_y[i]) if training else None, N, sp["cin"],
                         sp["cout"], S, st)
             flush()
-            if after_block and i in after_block:
-                after_block[i]()
             bn_done(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, f"stat_y{i}")
+            ev_feat = None  # the event a side stream waits for at this block, shared by everything forked here
             if i in pl.fpad:
                 plain = None
                 if want_features:
@@ -541,7 +540,7 @@ class Engine:
                 # (an unfolded one is finalised on the chain first, so its vectors are ready on either stream)
                 last = i == len(specs) - 1
                 if self.multi_stream and not last:
-                    ev = self._record(pl, f"fwd_feat{i}", st)
+                    ev = ev_feat = self._record(pl, f"fwd_feat{i}", st)
                     deferred.append(lambda ev=ev, i=i, materialize=materialize: (self._wait(stH, ev), materialize(stH),
                                                                                self._head_forward(pl, i, stH)))
                 else:
@@ -550,6 +549,8 @@ class Engine:
                         self._wait(st, ev_pack)
                         ev_pack = None
                     self._head_forward(pl, i, st)
+            if after_block and i in after_block:
+                after_block[i](ev_feat)  # (side work forked after this block waits for the same event: one record, not two)
         flush()
         if bn_layers:
             # running statistics and backward vectors of the folded BatchNorms: one launch on the MAIN stream (a hop to
@@ -751,7 +752,7 @@ class Engine:
                 self._k(f"pw_fwd{i}", "msl_pwconv_fwd_bf16", ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]),
                         ptr(blk.conv2.weight), ptr(pl.y[i]), part(pl.part_y[i]), N, sp["cin"], sp["cout"], S, st)
             if after_block and i in after_block:
-                after_block[i]()
+                after_block[i](None)
             if training and i in pl.feat_ids:  # the materialisation below reads the vectors
                 self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
             if i in pl.feat_ids and pl.f32_heads:
@@ -1192,8 +1193,6 @@ class Engine:
         packed = prepacked or (bool(side_feats) and self.batch_head_gpack)
         if packed and not prepacked:
             self._head_gpack_batch(pl, dlocs, dscores, st)
-        if side_feats:
-            self._fork(pl, "bwd_loss_ready", st, stH)
         L = _lib.load()
         pre_np = None  # set when the producer of the next activation gradient also produced its BatchNorm partials
         linked = False  # set when a channel link already applied the BatchNorm backward of the next layer's output gradient
@@ -1207,15 +1206,21 @@ class Engine:
                     tail.append(i)
             tail = tail[:4] if len(tail) >= 2 else []
         tail_args = []
+        ev_loss = None
         for f in pl.feat_ids:  # the chain's own scale first: its data gradient starts the backward chain
             if f not in side_feats:
                 if ms:
                     self._head_backward(pl, f, dlocs, dscores, st, weight=False, packed=packed)
-                    ev = self._record(pl, f"head_dO{f}", st)
+                    ev = ev_loss = self._record(pl, f"head_dO{f}", st)
                     pending.append(lambda f=f, ev=ev: (self._wait(stW, ev),
                                                        self._head_backward(pl, f, dlocs, dscores, stW, data=False)))
                 else:
                     self._head_backward(pl, f, dlocs, dscores, st, packed=packed)
+        if side_feats:
+            # the earlier scales' gradients (heads stream) need the head-gradient images
+            # (sharing the record behind the chain's own head bwd-data instead - one launch later, one record fewer - was
+            # measured 1-2 % SLOWER: the heads stream's gradients are as critical as the chain here)
+            self._fork(pl, "bwd_loss_ready", st, stH)
         for f in reversed(side_feats):  # the deeper scale is needed first
             pending.append(lambda f=f: self._head_backward(pl, f, dlocs, dscores, stH, self._event(pl, f"head_done{f}"), packed=packed))
         if wanted is not None and "heads" in wanted:
@@ -1254,6 +1259,10 @@ class Engine:
             link = link_nw > 0 and not fused_stem and np_red <= 0
             # (with <= 4 waves per channel the link takes the depthwise weight gradient along: no launch for it below)
             link_bww = link and link_nw <= 4
+            # a block whose pointwise weight gradient rides in the tail's batched launch (issued with the shallowest of them) and
+            # whose depthwise weight gradient the link produces has nothing waiting for dL/dz_i: no event record on the chain
+            idle_sink = link_bww and i in tail and i != tail[-1]
+            rec_here = rec_here and not idle_sink
             if not link:
                 self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
                 ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
@@ -1290,13 +1299,13 @@ class Engine:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
             def wgrads(ev_dz, i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, fused_stem=fused_stem or link_bww,
-                       ev_red=ev_red, ev_dy=ev_dy):
+                       ev_red=ev_red, ev_dy=ev_dy, idle_sink=idle_sink):
                 # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there
                 streams = [stW, stH, stX]
                 sX = streams[i % (self.split_wgrad + 1)] if ms else st
                 if ms and self.wgrad_on_heads is not None:  # experiment knob: explicit list of blocks for the heads stream
                     sX = stH if i in self.wgrad_on_heads else stW
-                if ms:  # the pointwise gradient needs dL/dy_i, the depthwise one dL/dz_i
+                if ms and not idle_sink:  # the pointwise gradient needs dL/dy_i, the depthwise one dL/dz_i
                     self._wait(sX, ev_dy if ev_dy is not None else ev_dz)
                 # partial sums only: slabs / fp64 partials stay in this layer's own buffers until Engine._grad_reduce
                 out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
@@ -1321,7 +1330,7 @@ class Engine:
                 fn()
             pending = []
             if ms:
-                sinks.append([i, wgrads, ev_dz])
+                sinks.append([i, wgrads, ev_dz if not idle_sink else "none"])
                 if ev_dz is not None:  # blocks that did not record wait for the next record of the chain instead
                     for ent in sinks:
                         if ent[2] is None:

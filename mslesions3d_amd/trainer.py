@@ -35,7 +35,9 @@ class FusedTrainer:
         self.max_programs = 16
         self._staging = {}         # (image shape, target capacity) -> persistent input buffers (see _stage)
         self._stream = None        # the step runs on its own stream (graph capture needs a non-default one)
-        self.match_after = int(os.environ.get("MSL_MATCH_AFTER", "4"))  # block after which the target matching is enqueued
+        # block after which the target matching is enqueued (a block that forks the heads stream anyway shares its event;
+        # A/B after block 4 / 5 at the end of round 3: equal within noise)
+        self.match_after = int(os.environ.get("MSL_MATCH_AFTER", "4"))
 
     def _reducer(self, arena):
         if self.reducer is None or self.reducer.arena is not arena:
@@ -70,8 +72,11 @@ class FusedTrainer:
             k = min(self.match_after, len(eng.layer_specs) - 1)  # (the hook of a block that does not exist would never fire)
             sM = eng.side_streams(dev)[1 if k > 0 else 0].cuda_stream
 
-            def run_match():
-                eng._fork(pl0, "match_start", main, sM)
+            def run_match(ev=None):
+                if ev is not None:  # the block forks the heads stream anyway: its event serves both (one record fewer)
+                    eng._wait(sM, ev)
+                else:
+                    eng._fork(pl0, "match_start", main, sM)
                 lf._run_match(st, N, gt_boxes, gt_labels, obj_off, total_objects, stream=sM, count=True)
             if k > 0:
                 after = {k: run_match}
