@@ -89,6 +89,20 @@ int msl_block_bwd_channel_link(float* g_z, const float* z, const float* vec_z, c
                                float* dbeta_y, float* dw_dw, int N, int C, int D, int H, int W, int stride, int accumulate,
                                void* stream);
 
+/* Pointwise backward of a big early block in one pass (autograd of mobilenet.py:45-47 for Block.conv2 / bn2 / bn1):
+ *   g_y (N,Cout,S) = dL/d relu(bn2(y)) (raw), y (N,Cout,S) raw conv2 output, bn_y_vec (>= 4, Cout) [scale, shift, mean, invstd],
+ *   y_partials fp64 [2][Cout][y_np] = the BatchNorm2-backward sums the producer of g_y emitted (msl_dwconv_bwd_data_bnreduce),
+ *   y_count = N*S  ->  dgamma_y / dbeta_y, and dL/dy applied on the fly (never stored);
+ *   g_z (N,Cin,S) = W^T . dL/dy (= dL/d relu(bn1(z)), raw), z_partials fp64 [2][Cin][NP] = BatchNorm1-backward sums of z
+ *   (for msl_bn_relu_bwd_finalize_apply), dw_slabs [NP][Cout][Cin] = partial sums of dL/dW (msl_grad_reduce kind 0);
+ *   NP = msl_pwconv_bwd_fused_num_partials (0: shape not taken - Cin = 32, Cout = 64, S % 128 == 0, >= 512 strips of 128
+ *   positions - use msl_bn_relu_bwd_* + msl_pwconv_bwd_data + msl_pwconv_bwd_weight_slabs; the entry returns -2). */
+int msl_pwconv_bwd_fused_num_partials(int N, int Cin, int Cout, int S);
+int msl_pwconv_bwd_fused(const float* g_y, const float* y, const float* bn_y_vec, const double* y_partials, int y_np,
+                         double y_count, float* dgamma_y, float* dbeta_y, const float* w, const float* z,
+                         const float* bn_z_vec, float* g_z, double* z_partials, float* dw_slabs, int N, int Cin, int Cout, int S,
+                         void* stream);
+
 /* ---- stem: Conv3d(Cin->32,k3,stride (sd,sh,sw),p1,no bias) : mobilenet.py:26-31 via ssd3d.py:60-61 ------- */
 int msl_stem_conv_fwd_num_partials(int N, int OD, int OH, int OW);
 int msl_stem_conv_fwd(const float* x, const float* w, float* y, double* partials, int N, int Cin, int D, int H,

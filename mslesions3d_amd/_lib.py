@@ -30,6 +30,8 @@ _SIGNATURES = {
     "msl_bn_relu_bwd_finalize_apply": (_I, [_P, _I, _D, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_bn_relu_bwd_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "msl_block_bwd_channel_link_supported": (_I, [_I, _I, _I, _I, _I]),
+    "msl_pwconv_bwd_fused_num_partials": (_I, [_I, _I, _I, _I]),
+    "msl_pwconv_bwd_fused": (_I, [_P, _P, _P, _P, _I, _D, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_block_bwd_channel_link": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_stem_conv_fwd_num_partials": (_I, [_I, _I, _I, _I]),
     "msl_stem_conv_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -214,6 +214,15 @@ class Plan:
                 npd = L.msl_dwconv_bwd_weight_num_partials(N, specs[i]["cin"], pd, ph, pw, specs[i]["stride"][0])
                 self.dw_np.append(npd)
                 self.dw_part.append(torch.empty(specs[i]["cin"] * 27 * npd, dtype=torch.float64, device=device))
+            # blocks whose whole pointwise backward is one pass (csrc/pwfused.hip): per block (slabs [NP][Cout][Cin], fp64
+            # statistics partials [2][Cin][NP], NP)
+            self.pw_fused = {}
+            for i in range(1, len(specs)):
+                D, H, W = self.dims[i]
+                nf = L.msl_pwconv_bwd_fused_num_partials(N, specs[i]["cin"], specs[i]["cout"], D * H * W)
+                if nf > 0:
+                    self.pw_fused[i] = (torch.empty(nf * specs[i]["cin"] * specs[i]["cout"], **f32),
+                                        torch.empty(2 * specs[i]["cin"] * nf, dtype=torch.float64, device=device), nf)
             self.head_nslabs = {f: L.msl_head_conv_bwd_weight_nslabs(N, specs[f]["cout"], *self.dims[f], ncls) for f in self.feat_ids}
             self.stem_nslabs = L.msl_stem_conv_bwd_weight_nslabs(N, *self.in_dims, *specs[0]["stride"])
             self.grad_tables = {}
@@ -232,6 +241,7 @@ class Plan:
         self.saved_input = None
         self.generation = 0
         self.dw_in_link = set()  # blocks whose depthwise weight gradient a channel link writes (no partials to fold)
+        self.pw_fused_used = set()  # blocks whose pointwise weight-gradient slabs came with the fused pointwise backward
 
 
 class Engine:
@@ -285,6 +295,7 @@ class Engine:
         self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", "32"))
         self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
         self.channel_link = True  # per-channel backward links of the tail blocks in one launch each (csrc/chanlink.hip)
+        self.fuse_pw_bwd = True   # whole pointwise backward of the big early block in one pass (csrc/pwfused.hip)
         self.side = {}
         self.arena = None
         self.plans = {}
@@ -1028,18 +1039,19 @@ class Engine:
                 ptr(pl.scores), ptr(pl.head_ws[f]), pl.N, C, D, H, W, pl.P, pl.prior_off[f], ncls, st)
 
     # ------------------------------------------------------------------------------------------------
-    def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st, pre_np=None, apply=True, coef=False):
+    def _bn_bwd(self, g, y, vec, bn_name, count, N, C, S, pl, st, pre_np=None, apply=True, coef=False, partials=None):
         """In place: g (= dL/d relu(bn(y))) becomes dL/dy; writes dgamma/dbeta into the gradient arena.
         ``pre_np``: the producer of g already emitted the reduce partials (pl.partials, that many per channel);
         ``apply=False``: the consumer applies the BatchNorm backward itself while loading (only c1/c2 are produced)."""
         L = _lib.load()
         gv = self.arena.grad_views
+        part = pl.partials if partials is None else partials  # (``partials``: where the producer left its pre_np sums)
         if pre_np is not None and coef:
-            _lib.call("msl_bn_bwd_finalize_coef", ptr(pl.partials), pre_np, float(count), ptr(gv[bn_name + ".weight"]),
+            _lib.call("msl_bn_bwd_finalize_coef", ptr(part), pre_np, float(count), ptr(gv[bn_name + ".weight"]),
                       ptr(gv[bn_name + ".bias"]), ptr(vec), C, st)
             return
         if pre_np is not None and apply and pre_np <= 256:
-            self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_finalize_apply", ptr(pl.partials), pre_np, float(count), ptr(g),
+            self._k("bn_bwd_apply:" + bn_name, "msl_bn_relu_bwd_finalize_apply", ptr(part), pre_np, float(count), ptr(g),
                     ptr(y), ptr(vec), ptr(gv[bn_name + ".weight"]), ptr(gv[bn_name + ".bias"]), ptr(g), N, C, S, st)
             return
         if pre_np is not None:
@@ -1241,14 +1253,27 @@ class Engine:
             # then the depthwise gradients.  The host enqueues the dependency chain (main stream) FIRST and the two
             # weight gradients (wgrad stream, waiting on events recorded in the chain) afterwards: the chain is made of
             # ~10 us kernels, so any launch queued in front of its next link shows up as idle time.
-            if not linked:  # (a channel link of block i+1 has already turned g_y[i] into dL/dy_i)
+            # big early block whose producer left the BatchNorm2-backward sums: BatchNorm backward of y_i (applied on load),
+            # bwd-data GEMM, BatchNorm1-backward sums of z_i and the pointwise weight gradient in ONE pass (csrc/pwfused.hip)
+            pw_fused = (self.fuse_pw_bwd and not linked and pre_np is not None and i in pl.pw_fused
+                        and 2 * sp["cout"] * pre_np <= pl.partials.numel())
+            z_np = None
+            if pw_fused:
+                slabs_f, part_f, z_np = pl.pw_fused[i]
+                self._k(f"pw_bwd_fused{i}", "msl_pwconv_bwd_fused", ptr(pl.g_y[i]), ptr(pl.y[i]), ptr(pl.bn_y[i]), ptr(pl.partials),
+                        pre_np, float(N * S), ptr(gv[name + ".bn2.weight"]), ptr(gv[name + ".bn2.bias"]),
+                        ptr(feats[i].conv2.weight), ptr(pl.z[i]), ptr(pl.bn_z[i]), ptr(pl.g_z[i]), ptr(part_f), ptr(slabs_f), N,
+                        sp["cin"], sp["cout"], S, st)
+                pl.pw_fused_used.add(i)
+            elif not linked:  # (a channel link of block i+1 has already turned g_y[i] into dL/dy_i)
                 self._bn_bwd(pl.g_y[i], pl.y[i], pl.bn_y[i], name + ".bn2", N * S, N, sp["cout"], S, pl, st, pre_np=pre_np)
             pre_np, linked = None, False
             # dL/dy_i is final here: the pointwise weight gradient may start two or three chain kernels before dL/dz_i is
             rec_here = self.wgrad_record_at is None or i in self.wgrad_record_at or i == 1
-            ev_dy = self._record(pl, f"dy{i}", st) if ms and self.early_pw_bww and rec_here else None
-            self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N, sp["cin"],
-                    sp["cout"], S, st)
+            ev_dy = self._record(pl, f"dy{i}", st) if ms and self.early_pw_bww and rec_here and not pw_fused else None
+            if not pw_fused:
+                self._k(f"pw_bwd{i}", "msl_pwconv_bwd_data", ptr(pl.g_y[i]), ptr(feats[i].conv2.weight), ptr(pl.g_z[i]), N,
+                        sp["cin"], sp["cout"], S, st)
             accumulate = 1 if (i - 1) in pl.fpad else 0  # the heads already wrote their share
             Sp = pd * ph * pw
             np_red = L.msl_dwconv_bwd_data_bnreduce_num_partials(N, sp["cin"], pd, ph, pw) if (s == 2 and N * Sp > 65536) else -1
@@ -1256,15 +1281,16 @@ class Engine:
             # tail of the network: BatchNorm1 backward of z_i, depthwise bwd-data (+ the heads' share) and BatchNorm2 backward
             # of y_{i-1} are all per channel and a channel's population fits one workgroup: ONE launch (csrc/chanlink.hip)
             link_nw = L.msl_block_bwd_channel_link_supported(N, pd, ph, pw, s) if self.channel_link else 0
-            link = link_nw > 0 and not fused_stem and np_red <= 0
+            link = link_nw > 0 and not fused_stem and np_red <= 0 and not pw_fused
             # (with <= 4 waves per channel the link takes the depthwise weight gradient along: no launch for it below)
             link_bww = link and link_nw <= 4
             # a block whose pointwise weight gradient rides in the tail's batched launch (issued with the shallowest of them) and
             # whose depthwise weight gradient the link produces has nothing waiting for dL/dz_i: no event record on the chain
-            idle_sink = link_bww and i in tail and i != tail[-1]
+            idle_sink = (link_bww and i in tail and i != tail[-1]) or (pw_fused and fused_stem)
             rec_here = rec_here and not idle_sink
             if not link:
-                self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st)
+                self._bn_bwd(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N * S, N, sp["cin"], S, pl, st, pre_np=z_np,
+                             partials=pl.pw_fused[i][1] if pw_fused else None)
                 ev_dz = self._record(pl, f"dz{i}", st) if ms and rec_here else None
             if accumulate and (i - 1) in side_feats:
                 self._wait(st, pl.events[f"head_done{i - 1}"])
@@ -1299,7 +1325,7 @@ class Engine:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
             def wgrads(ev_dz, i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, fused_stem=fused_stem or link_bww,
-                       ev_red=ev_red, ev_dy=ev_dy, idle_sink=idle_sink):
+                       ev_red=ev_red, ev_dy=ev_dy, idle_sink=idle_sink, pw_fused=pw_fused):
                 # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there
                 streams = [stW, stH, stX]
                 sX = streams[i % (self.split_wgrad + 1)] if ms else st
@@ -1309,7 +1335,9 @@ class Engine:
                     self._wait(sX, ev_dy if ev_dy is not None else ev_dz)
                 # partial sums only: slabs / fp64 partials stay in this layer's own buffers until Engine._grad_reduce
                 out = pl.pw_slabs[i] if pl.pw_nslabs[i] > 1 else gv[name + ".conv2.weight"]
-                if i in tail:
+                if pw_fused:
+                    pass  # (its slabs came with the fused pointwise backward)
+                elif i in tail:
                     tail_args.append((ptr(pl.g_y[i]), ptr(pl.z[i]), ptr(pl.bn_z[i][0]), ptr(pl.bn_z[i][1]), ptr(out), sp["cin"],
                                       sp["cout"], S))
                     if i == tail[-1]:  # the shallowest: every dL/dy of the group is final (same chain, earlier)
@@ -1425,7 +1453,9 @@ class Engine:
             for i in range(len(specs) - 1, 0, -1):
                 name = f"base.features.{i}"
                 cnt = specs[i]["cin"] * specs[i]["cout"]
-                if want(name + ".conv2.weight") and pl.pw_nslabs[i] > 1:
+                if want(name + ".conv2.weight") and i in getattr(pl, "pw_fused_used", ()):
+                    rows.append((0, pl.pw_fused[i][0], gv[name + ".conv2.weight"], None, pl.pw_fused[i][2], cnt, cnt, 0, 0, 0))
+                elif want(name + ".conv2.weight") and pl.pw_nslabs[i] > 1:
                     rows.append((0, pl.pw_slabs[i], gv[name + ".conv2.weight"], None, pl.pw_nslabs[i], cnt, cnt, 0, 0, 0))
                 if want(name + ".conv1.weight") and i not in getattr(pl, "dw_in_link", ()):  # (a channel link wrote it)
                     if i == 1 and fused:

@@ -808,3 +808,67 @@ def test_block_bwd_channel_link_refuses_what_it_cannot_hold():
     rc = L.msl_block_bwd_channel_link(ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), ptr(x), None, 2, 8, 6, 6,
                                       6, 1, 0, st())
     assert rc == -2
+
+
+# ------------------------------------------------------------------------------------------------- fused pointwise backward
+@pytest.mark.parametrize("n,s_dims", [(2, (32, 32, 32)), (4, (16, 32, 32))])
+def test_pwconv_bwd_fused_matches_autograd(n, s_dims):
+    """msl_pwconv_bwd_fused (block 1's whole pointwise backward in one pass) against torch autograd of
+    relu(bn2(conv1x1(relu(bn1(z))))) with train-mode BatchNorms (mobilenet.py:45-47): dL/d relu(bn1(z)), the BatchNorm1-backward
+    sums of z, dgamma / dbeta of bn2 and the 1x1x1 weight gradient; the BatchNorm2-backward sums come in as partials."""
+    L = _lib.load()
+    cin, cout = 32, 64
+    S = s_dims[0] * s_dims[1] * s_dims[2]
+    NP = L.msl_pwconv_bwd_fused_num_partials(n, cin, cout, S)
+    assert NP == 256
+    assert L.msl_pwconv_bwd_fused_num_partials(n, 64, 128, S) == 0 and L.msl_pwconv_bwd_fused_num_partials(1, cin, cout, 4096) == 0
+    z = rnd(n, cin, *s_dims, seed=1).requires_grad_(True)
+    bn1, bn2 = torch.nn.BatchNorm3d(cin), torch.nn.BatchNorm3d(cout)
+    conv = torch.nn.Conv3d(cin, cout, 1, bias=False)
+    with torch.no_grad():
+        for i, bn in enumerate((bn1, bn2)):
+            bn.weight.copy_(torch.rand(bn.num_features, generator=torch.Generator().manual_seed(10 + i)) + 0.5)
+            bn.bias.copy_(rnd(bn.num_features, seed=20 + i, scale=0.3))
+        conv.weight.copy_(rnd(cout, cin, 1, 1, 1, seed=3, scale=0.2))
+    a1 = torch.relu(bn1(z))
+    a1.retain_grad()
+    y = conv(a1)
+    y.retain_grad()
+    out = torch.relu(bn2(y))
+    G = rnd(*out.shape, seed=4)
+    (out * G).sum().backward()
+
+    def vec(x, bn):
+        mean, var = x.mean(dim=(0, 2, 3, 4)), x.var(dim=(0, 2, 3, 4), unbiased=False)
+        inv = 1.0 / torch.sqrt(var + bn.eps)
+        sc = bn.weight * inv
+        return torch.stack([sc, bn.bias - mean * sc, mean, inv]).detach()
+    vy, vz = vec(y, bn2), vec(z, bn1)
+    # the BatchNorm2-backward sums as a producer would leave them: [2][cout][np] partials (here: split over 5 parts)
+    yd = y.detach()
+    gm = torch.where(yd * vy[0].view(1, -1, 1, 1, 1) + vy[1].view(1, -1, 1, 1, 1) > 0, G, torch.zeros_like(G)).double()
+    xh = ((yd - vy[2].view(1, -1, 1, 1, 1)) * vy[3].view(1, -1, 1, 1, 1)).double()
+    ynp = 5
+    parts = torch.zeros(2, cout, ynp, dtype=torch.float64)
+    flat_g, flat_x = gm.transpose(0, 1).reshape(cout, -1), (gm * xh).transpose(0, 1).reshape(cout, -1)
+    for p_, (a, b) in enumerate(zip(flat_g.chunk(ynp, dim=1), flat_x.chunk(ynp, dim=1))):
+        parts[0, :, p_], parts[1, :, p_] = a.sum(1), b.sum(1)
+    gz = K(torch.zeros(n, cin, *s_dims))
+    zpart = K(torch.zeros(2 * cin * NP, dtype=torch.float64))
+    slabs = K(torch.zeros(NP * cout * cin))
+    dgam, dbet = K(torch.zeros(cout)), K(torch.zeros(cout))
+    _lib.call("msl_pwconv_bwd_fused", ptr(K(G)), ptr(K(y)), ptr(K(vy)), ptr(K(parts)), ynp, float(n * S), ptr(dgam), ptr(dbet),
+              ptr(K(conv.weight)), ptr(K(z)), ptr(K(vz)), ptr(gz), ptr(zpart), ptr(slabs), n, cin, cout, S, st())
+    close(gz, a1.grad, 2e-4, 2e-5 * float(a1.grad.abs().max()), "dL/d relu(bn1(z))")
+    close(dgam, bn2.weight.grad, 2e-4, 1e-5 * float(bn2.weight.grad.abs().max()), "dgamma bn2")
+    close(dbet, bn2.bias.grad, 2e-4, 1e-5 * float(bn2.bias.grad.abs().max()), "dbeta bn2")
+    dw = slabs.view(NP, cout, cin).double().sum(0)
+    close(dw, conv.weight.grad.view(cout, cin), 3e-4, 3e-5 * float(conv.weight.grad.abs().max()), "1x1x1 weight gradient")
+    zs = zpart.view(2, cin, NP).sum(-1).cpu()
+    close(zs[0], bn1.bias.grad, 3e-4, 1e-5 * float(bn1.bias.grad.abs().max()), "sum gm of bn1 (= dbeta)")
+    close(zs[1], bn1.weight.grad, 3e-4, 1e-5 * float(bn1.weight.grad.abs().max()), "sum gm * xhat of bn1 (= dgamma)")
+    # run-to-run bit-identical
+    gz2, zpart2, slabs2 = K(torch.zeros_like(gz)), K(torch.zeros_like(zpart)), K(torch.zeros_like(slabs))
+    _lib.call("msl_pwconv_bwd_fused", ptr(K(G)), ptr(K(y)), ptr(K(vy)), ptr(K(parts)), ynp, float(n * S), ptr(dgam), ptr(dbet),
+              ptr(K(conv.weight)), ptr(K(z)), ptr(K(vz)), ptr(gz2), ptr(zpart2), ptr(slabs2), n, cin, cout, S, st())
+    assert torch.equal(gz, gz2) and torch.equal(zpart, zpart2) and torch.equal(slabs, slabs2)
