@@ -44,6 +44,12 @@ def parse():
     ap.add_argument("--train-steps", type=int, default=300, help="infer mode: optimisation steps before the timed inference "
                     "(random-init weights never see a cube otherwise; outside the timed region)")
     ap.add_argument("--map-cases", type=int, default=8, help="infer mode: synthetic cases scored for mAP@0.1 / 0.5")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
+                    help="set a schedule option of the engine / trainer / launch-program replayer for A/B runs, e.g. --opt "
+                         "fold_np_max=64 --opt match_after=5 (plain attributes of mslesions3d_amd.engine.Engine, trainer.FusedTrainer, "
+                         "_lib; echoed under 'knobs').  The library itself reads no tuning environment variables.")
+    ap.add_argument("--fence", action="store_true", help="bracket every step with stream hand-offs to the caller's stream (default: "
+                    "the steps of the timed region are enqueued back to back on the trainer's stream)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=25)  # ~10 s of CPU work
     ap.add_argument("--no-aggregate", action="store_true",
@@ -52,6 +58,33 @@ def parse():
     ap.add_argument("--no-events", action="store_true", help="no HIP-event pair around the roofline kernel inside the timed steps")
     ap.add_argument("--profile-all", action="store_true", help="HIP-event time every launch and print a table (stderr)")
     return ap.parse_args()
+
+
+def apply_opts(opts, *targets):
+    """--opt name=value -> setattr on the first target that has the attribute (int / float / bool / 'a,b' set / string)."""
+    done = {}
+    for item in opts:
+        name, _, raw = item.partition("=")
+        if raw.lower() in ("true", "false"):
+            val = raw.lower() == "true"
+        elif raw.lower() == "none":
+            val = None
+        else:
+            try:
+                val = int(raw)
+            except ValueError:
+                try:
+                    val = float(raw)
+                except ValueError:
+                    val = {int(v) for v in raw.split(",")} if "," in raw and raw.replace(",", "").isdigit() else raw
+        for t in targets:
+            if hasattr(t, name):
+                setattr(t, name, val)
+                done[name] = raw
+                break
+        else:
+            raise SystemExit(f"--opt {name}: no such option on {[type(t).__name__ for t in targets]}")
+    return done
 
 
 def cpu_baseline(size, batch, channels, steps):
@@ -273,6 +306,7 @@ def main():
     model._engine.ensure_arena(dev)
     broadcast_model(model)
     trainer = FusedTrainer(model)
+    opts = apply_opts(args.opt, model._engine, trainer, _lib)
 
     # a small pool of resident batches (different volumes per rank: weak scaling, independent shards)
     pool = []
@@ -285,7 +319,7 @@ def main():
             x, gb, gl, off, T = pool[s % len(pool)]
             # the steps of a run are enqueued back to back on the trainer's stream (fence=False: no per-step round trip
             # through the caller's stream); torch.cuda.synchronize() on both sides of the timed region orders everything else
-            trainer.step_packed(x, gb, gl, off, T, sync=False, resident=True, fence=os.environ.get("MSL_BENCH_FENCE", "0") == "1")
+            trainer.step_packed(x, gb, gl, off, T, sync=False, resident=True, fence=args.fence)
 
     run(args.warmup)
     torch.cuda.synchronize()
@@ -411,7 +445,7 @@ def main():
                          "frac_rocprof": frac_rocprof,
                          "traffic": traffic, "traffic_source": traffic_src, "algorithmic_bytes_per_launch": alg_bytes,
                          "avg_launch_us": round(avg_ms * 1e3, 2), "launches_timed": len(ms)},
-            "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MSL_")},
+            "knobs": dict({k: v for k, v in sorted(os.environ.items()) if k.startswith("MSL_")}, **opts),
         }
         if dw_all and all(dw_all.get(f"dw_fwd{i}") for i in range(1, 8)):
             # block i reads (N, C_i, dims[i-1]) and writes (N, C_i, dims[i]) once, plus its taps

@@ -177,6 +177,7 @@ def new_event():
 
 
 # -- native replay ----------------------------------------------------------------------------------------------
+ENQUEUE_THREADS = 2  # host threads issuing a replayed launch program (2: the side streams' calls go to a worker thread)
 _SLOT_STRIDE = 28
 _fn_ids = {}
 
@@ -207,9 +208,9 @@ def compile_program(prog, timed_tags=(), main_stream=None, device=0):
 
     ``main_stream``: issue the segment with two host threads (msl_run_program_mt) - the calls on that stream stay with
     the caller, everything else goes to the worker thread; a stream-wait is held back until the event record it refers
-    to has been issued.  None (or MSL_ENQUEUE_THREADS=1): one thread."""
+    to has been issued.  None (or ``ENQUEUE_THREADS = 1``): one thread."""
     lib = load()
-    two = main_stream is not None and os.environ.get("MSL_ENQUEUE_THREADS", "2") != "1"
+    two = main_stream is not None and ENQUEUE_THREADS != 1
     segs, ids, slots, tags, patches, lanes, waits = [], [], [], [], [], [], []
     last_record = {}
 

@@ -379,9 +379,9 @@ __global__ __launch_bounds__(256) void pw_bf16_tr_kernel(const u16* __restrict__
   }
 }
 
-// the pipelined transposed-read kernel takes maps of whole 8-position groups and K in whole chunks (MSL_BF16_PW_TR=0: never)
+// the pipelined transposed-read kernel takes maps of whole 8-position groups and K in whole chunks (always, when the shape allows)
 static bool pw_tr_ok(int M, int K, int S) {
-  static const int on = getenv("MSL_BF16_PW_TR") ? atoi(getenv("MSL_BF16_PW_TR")) : 1;
+  constexpr int on = 1;
   return on && S % 8 == 0 && K % 32 == 0 && K <= PB_MAXK && M % 8 == 0;
 }
 template <bool STATS, bool TRANS_W>
@@ -814,8 +814,8 @@ __global__ __launch_bounds__(NT) void bn_relu_bwd_fused_reg_bf16_kernel(const u1
 
 extern "C" {
 
-static bool dw_bf16_use_wave() {  // MSL_BF16_DW_WAVE=0: always the LDS-tiled any-shape kernels (A/B and tests)
-  static const int on = getenv("MSL_BF16_DW_WAVE") ? atoi(getenv("MSL_BF16_DW_WAVE")) : 1;
+static bool dw_bf16_use_wave() {  // (the LDS-tiled any-shape kernels take what the wave kernels do not)
+  constexpr int on = 1;
   return on != 0;
 }
 

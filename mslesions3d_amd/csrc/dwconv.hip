@@ -1417,7 +1417,7 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
   const int RS = stride == 1 ? W + 8 : ((OW + 3) & ~3) + ((OW + 4) & ~3);
   const int PS = (H + 2) * RS;
   const int OWV = OW / 4, Lp = OH * OWV;
-  static const int stream_min_hw = getenv("MSL_DW_STREAM_MIN_HW") ? atoi(getenv("MSL_DW_STREAM_MIN_HW")) : 1024;
+  constexpr int stream_min_hw = 1024;
   if (H * W >= stream_min_hw) {  // stream
     int G = 1;
     int ipt = msl::cdiv(G * Lp, 256);
@@ -1437,10 +1437,6 @@ DwPlan make_plan(int N, int C, int D, int H, int W, int stride) {
     int slabs = std::max(1, std::min(OD, 1024 / std::max(1, nvol)));
     int SLAB = msl::cdiv(OD, slabs);
     if (SLAB < 4) SLAB = std::min(4, OD);
-    if (const char* e = getenv("MSL_DW_STREAM_SLAB")) {  // tuning knob (tools/bench_dw.py); default: 4 planes
-      const int v = atoi(e);
-      if (v > 0) SLAB = std::min(v, OD);
-    }
     pl.SLAB = SLAB;
     pl.nslabs = msl::cdiv(OD, SLAB);
     pl.lds_bytes = lds;
@@ -1480,12 +1476,12 @@ struct WavePlan {
 };
 
 WavePlan make_wave_plan(int N, int C, int D, int H, int W, int stride) {
-  static const int enabled = getenv("MSL_DW_WAVE") ? atoi(getenv("MSL_DW_WAVE")) : 3;  // bit 0: stride 1, bit 1: stride 2
+  constexpr int enabled = 3;  // bit 0: stride 1, bit 1: stride 2
   WavePlan wp{};
   if (!enabled || H != W) return wp;
   if (stride == 2) {
-    // MSL_DW_WAVE_S2_MAXW=32 sends block 1's 64^2 planes back to the streamed kernel (A/B: tools/ab_dw_wave.sh)
-    static const int maxw = getenv("MSL_DW_WAVE_S2_MAXW") ? atoi(getenv("MSL_DW_WAVE_S2_MAXW")) : 64;
+    // (planes up to 64^2: with 32 block 1's 64^2 planes go back to the streamed kernel - slower, tools/ab_dw_wave.sh in round 1)
+    constexpr int maxw = 64;
     if ((W != 8 && W != 16 && W != 32 && W != 64) || W > maxw || !(enabled & 2)) return wp;
     wp.logw4 = W == 8 ? 1 : W == 16 ? 2 : W == 32 ? 3 : 4;
     wp.logh = wp.logw4 + 1;  // log2(OH)
@@ -1494,7 +1490,7 @@ WavePlan make_wave_plan(int N, int C, int D, int H, int W, int stride) {
     wp.wpp = cells >= 64 ? cells / 64 : 1;
     if (C % wp.cpw != 0) return wp;
     wp.SL = OD >= 8 ? 4 : OD >= 4 ? 2 : 1;
-    static const int sl2 = getenv("MSL_DW_WAVE_SL2") ? atoi(getenv("MSL_DW_WAVE_SL2")) : 0;  // tuning knob: cap
+    constexpr int sl2 = 0;  // tuning knob: cap
     if (sl2 > 0) wp.SL = std::min(wp.SL, sl2 >= 4 ? 4 : sl2 >= 2 ? 2 : 1);
     wp.nslabs = msl::cdiv(OD, wp.SL);
     if ((long long)N * (C / wp.cpw) * wp.nslabs * wp.wpp > (1ll << 30)) return wp;
@@ -1508,7 +1504,7 @@ WavePlan make_wave_plan(int N, int C, int D, int H, int W, int stride) {
   wp.cpw = 64 / (H * W / 4);
   if (C % wp.cpw != 0) return wp;
   wp.SL = D >= 16 ? 8 : D >= 8 ? 4 : D >= 4 ? 2 : 1;
-  static const int sl1 = getenv("MSL_DW_WAVE_SL1") ? atoi(getenv("MSL_DW_WAVE_SL1")) : 0;  // tuning knob: cap
+  constexpr int sl1 = 0;  // tuning knob: cap
   if (sl1 > 0) wp.SL = std::min(wp.SL, sl1 >= 8 ? 8 : sl1 >= 4 ? 4 : sl1 >= 2 ? 2 : 1);
   wp.nslabs = msl::cdiv(D, wp.SL);
   if ((long long)N * (C / wp.cpw) * wp.nslabs > (1ll << 30)) return wp;
@@ -1562,9 +1558,9 @@ void launch_wave_s2(const WavePlan& wp, const T* x, const float* in_scale, const
 }
 
 // eval-mode forward on dw_s2_rows_eval_kernel / dw_s1_rows_eval_kernel: no statistics, planes the power-of-two wave kernels do not take
-// (MSL_DW_ROWS_EVAL=0 sends them back to the LDS kernels)
+// (the LDS kernels remain for the shapes these do not take)
 bool rows_eval_ok(int N, int C, int D, int H, int W, int stride) {
-  static const int on = getenv("MSL_DW_ROWS_EVAL") ? atoi(getenv("MSL_DW_ROWS_EVAL")) : 1;
+  constexpr int on = 1;
   if (!on || W % 4 != 0 || W < 8 || W > 256 || D < 2) return false;
   if (stride == 2 && H % 2 != 0) return false;
   if (make_wave_plan(N, C, D, H, W, stride).ok) return false;
@@ -1604,9 +1600,9 @@ void launch_rows_eval(const T* x, const float* in_scale, const float* in_shift, 
   }
 }
 
-// weight gradient on the wave kernels (MSL_DW_WAVE_BWW=0 sends it back to the LDS-tiled / generic kernels)
+// weight gradient on the wave kernels (the LDS-tiled / generic kernels remain for the other shapes)
 bool wave_bww_enabled() {
-  static const int on = getenv("MSL_DW_WAVE_BWW") ? atoi(getenv("MSL_DW_WAVE_BWW")) : 1;
+  constexpr int on = 1;
   return on != 0;
 }
 

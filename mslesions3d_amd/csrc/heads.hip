@@ -886,7 +886,7 @@ __global__ __launch_bounds__(256) void head_bww_lds_kernel(const float* __restri
 // the LDS-staged kernels take cubic W = H in {4, 8, 16} feature maps (W = 4: whole groups of 4 planes) and 16 output
 // channels (12 + 2*2: two classes)
 inline int head_lds_w(int C, int D, int H, int W, int MT = 1) {
-  static const int on = getenv("MSL_HEAD_LDS") ? atoi(getenv("MSL_HEAD_LDS")) : 1;
+  constexpr int on = 1;
   if (!on || MT != 1 || H != W || C % 16 != 0 || (D * H * W) % 64 != 0) return 0;
   if (W == 16 || W == 8) return W;
   if (W == 4 && D % 4 == 0) return 4;
@@ -992,7 +992,7 @@ inline HwPlan head_bw_plan(int N, int C, int D, int H, int W, int MT) {
   const int S = D * H * W, tiles = (C / 16) * 3;
   HwPlan p;
   p.lds_w = head_lds_w(C, D, H, W, MT);
-  static const int target = getenv("MSL_HEAD_BWW_WGS") ? atoi(getenv("MSL_HEAD_BWW_WGS")) : 256;
+  constexpr int target = 256;
   const int want_blocks = std::max(1, target / tiles);
   if (p.lds_w) {
     const int total = N * (S / 64);
@@ -1011,10 +1011,10 @@ inline HwPlan head_bw_plan(int N, int C, int D, int H, int W, int MT) {
 inline int head_fwd_ksg(int N, int C, int D, int H, int W, int MT) {
   const int S = D * H * W;
   if (head_lds_w(C, D, H, W, MT)) {
-    // about one workgroup per CU.  More (MSL_HEAD_FWD_WGS / _BWD_WGS / _BWW_WGS = 512, 768: a second wave per SIMD to cover the
+    // about one workgroup per CU.  More (512, 768 for the forward / bwd-data / weight-gradient kernels: a second wave per SIMD to cover the
     // loop's LDS-read waits) was measured 0.5-1.5 % SLOWER on the step (tools/probes/r02_headwgs.sh): the extra staging and
     // partial slabs cost what the latency hiding gains
-    static const int target = getenv("MSL_HEAD_FWD_WGS") ? atoi(getenv("MSL_HEAD_FWD_WGS")) : 256;
+    constexpr int target = 256;
     const int blocks = N * (S / 64);
     int ksg = 1;
     while (blocks * ksg < target && C / (ksg * 2) >= HEAD_FWD_CH && (C / (ksg * 2)) % HEAD_FWD_CH == 0) ksg *= 2;
@@ -1164,7 +1164,7 @@ static int head_bwd_data_impl(const float* dO_pad, const float* Wb, void* g_a, i
   hipStream_t st = (hipStream_t)stream;
   const int lw = head_lds_w(C, D, H, W, MT);
   if (lw) {
-    static const int target = getenv("MSL_HEAD_BWD_WGS") ? atoi(getenv("MSL_HEAD_BWD_WGS")) : 256;
+    constexpr int target = 256;
     const int blocks = N * (S / 64), ctiles = C / 16;
     const int gy = std::max(1, std::min(ctiles, target / blocks));
     const int cts = msl::cdiv(ctiles, gy);

@@ -601,7 +601,7 @@ __global__ __launch_bounds__(256) void pw_strip_kernel(const float* __restrict__
 // which (K, M, S) take the column-strip kernel, and with which strip width (0: none): the forward and bwd-data GEMMs of
 // blocks 1-3 (K = input channels of the GEMM, M = output rows)
 static inline int strip_cols(int N, int K, int M, int S) {
-  static const int on = getenv("MSL_PW_STRIP") ? atoi(getenv("MSL_PW_STRIP")) : 1;
+  constexpr int on = 1;
   if (!on) return 0;
   int cols = 0;
   if (K == 32 && M == 64) cols = 256;
@@ -632,7 +632,7 @@ static int launch_strip(const float* X, const float* in_scale, const float* in_s
 // column tiles per wave of the unsplit form (K <= 64): two when that still leaves >= 2 waves per SIMD - the weight rows, the
 // input affine and the statistics reduction are then paid once per 64 columns
 static inline int wave_nt(int N, int K, int M, int S) {
-  static const int force = getenv("MSL_PW_NT") ? atoi(getenv("MSL_PW_NT")) : 0;
+  constexpr int force = 0;
   if (K > 64) return 1;
   if (force) return force;
   const int mt = (M % 64 == 0) ? 2 : 1;
@@ -949,7 +949,7 @@ struct BwwWavePlan {
 
 // Supported: whole 32-position chunks and 32-channel tiles.  nslabs == 1 -> the kernel writes dW itself.
 static inline bool bww_wave_plan(int N, int Cin, int Cout, int S, BwwWavePlan& p) {
-  static const int off = getenv("MSL_PW_BWW_WAVE") ? atoi(getenv("MSL_PW_BWW_WAVE")) : 1;
+  constexpr int off = 1;
   if (!off || S % 32 != 0 || Cin % 32 != 0 || Cout % 32 != 0) return false;
   p.mt = (Cout % 64 == 0) ? 2 : 1;
   p.tiles = (Cout / (32 * p.mt)) * (Cin / 32);
@@ -957,7 +957,7 @@ static inline bool bww_wave_plan(int N, int Cin, int Cout, int S, BwwWavePlan& p
   p.total_chunks = N * p.chunks_per_img;
   // position split: about one workgroup per CU in total, at least 8 chunks (2 per wave) each - every split costs a
   // Cout x Cin slab written and read back
-  static const int target = getenv("MSL_PW_BWW_WGS") ? atoi(getenv("MSL_PW_BWW_WGS")) : 256;
+  constexpr int target = 256;
   int ks = std::max(1, std::min(target / std::max(1, p.tiles), p.total_chunks / 8));
   p.chunks_per_block = msl::cdiv(p.total_chunks, ks);
   p.ksplit = msl::cdiv(p.total_chunks, p.chunks_per_block);
@@ -987,7 +987,7 @@ BwPlan bw_plan(int N, int Cin, int Cout, int S) {
   // written and read back (a 256-way split of block 2 moved 8 MB of slabs for 12 MB of operands), and this kernel
   // runs on the weight-gradient stream beside the dependency chain, where fewer, longer workgroups interfere less
   int ks = std::max(1, std::min(total, 512 / std::max(1, tiles)));
-  static const int min_cpb = getenv("MSL_PW_BWW_MIN_CPB") ? atoi(getenv("MSL_PW_BWW_MIN_CPB")) : 1;
+  constexpr int min_cpb = 1;
   ks = std::max(1, std::min(ks, total / std::max(1, min_cpb)));
   p.chunks_per_block = msl::cdiv(total, ks);
   p.ksplit = msl::cdiv(total, p.chunks_per_block);

@@ -1147,9 +1147,9 @@ __global__ __launch_bounds__(256) void stem_bwd_weight_reduce_kernel(const float
 }
 
 constexpr int STEM_BW_BLOCKS = 512;
-// workgroups of the stem weight gradient (= partial slabs): two per CU by default; MSL_STEM_BWW_BLOCKS for A/B
+// workgroups of the stem weight gradient (= partial slabs): two per CU
 static inline int stem_bw_blocks() {
-  static const int v = getenv("MSL_STEM_BWW_BLOCKS") ? atoi(getenv("MSL_STEM_BWW_BLOCKS")) : STEM_BW_BLOCKS;
+  constexpr int v = STEM_BW_BLOCKS;
   return v > 0 ? v : STEM_BW_BLOCKS;
 }
 
@@ -1158,7 +1158,7 @@ static inline int stem_bw_blocks() {
 extern "C" {
 
 static inline int stem_fwd_blocks(int OD, int OH, int OW) {
-  static const int per_image = getenv("MSL_STEM_FWD_BLOCKS") ? atoi(getenv("MSL_STEM_FWD_BLOCKS")) : STEM_FWD_BLOCKS_PER_IMAGE;
+  constexpr int per_image = STEM_FWD_BLOCKS_PER_IMAGE;
   return std::min(per_image, msl::cdiv(OD * OH * msl::cdiv(OW, 64), 4));
 }
 
@@ -1176,7 +1176,7 @@ static int stem_fwd_impl(const float* x, const float* w, void* y, double* partia
   const int iters = msl::cdiv(chunks_per_n, nb * 4);
   dim3 grid(nb, N);
   hipStream_t st = (hipStream_t)stream;
-  static const int rows_on = getenv("MSL_STEM_FWD_ROWS") ? atoi(getenv("MSL_STEM_FWD_ROWS")) : 1;
+  constexpr int rows_on = 1;
   if (rows_on && sw == 2 && W % 4 == 0 && OW % 32 == 0 && Cin <= 2) {
     // row-staged form (contiguous 16-byte row loads, operands from LDS)
     const size_t lds = (size_t)4 * 2 * Cin * 9 * SFR_RP * sizeof(float);
@@ -1311,7 +1311,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
   const int NT = (Cin * 27 + 31) / 32;
   const size_t lds = (size_t)4 * (32 * SB_DY_LD + Cin * 9 * SB_ROW_LD) * sizeof(float);
   const StemFusedSrc fs{(OD - 1) / 2 + 1, (OH - 1) / 2 + 1, (OW - 1) / 2 + 1};
-  static const int tile_on = getenv("MSL_STEM_BWW_TILE") ? atoi(getenv("MSL_STEM_BWW_TILE")) : 1;
+  constexpr int tile_on = 1;
   if (tile_on && w1 && sd == 2 && sh == 2 && sw == 2 && W == 128 && H % 16 == 0 && Cin <= 2 &&
       (long long)N * Cin * D * H * W * 4 < (1ll << 32)) {
     // tile-staged form (stem_bww_tile_kernel): a workgroup per 4 output rows of one parity; same slab count as below
@@ -1319,7 +1319,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
     const int nb = std::min(stem_bw_blocks(), tiles_total);
     const int it = msl::cdiv(tiles_total, nb);
     const size_t tl = (size_t)(32 * SBT_LDA + 36 * Cin * SBT_RP) * sizeof(float);
-    static const int tile_nw = getenv("MSL_STEM_BWW_NW") ? atoi(getenv("MSL_STEM_BWW_NW")) : 4;
+    constexpr int tile_nw = 4;
 #define MSL_STEM_BWT2(CI, B_, NW_)                                                                                   \
   do {                                                                                                               \
     if (tl > 64 * 1024) {                                                                                            \

@@ -254,48 +254,38 @@ class Engine:
 
     def __init__(self, model):
         self.model = model
+        # ---- schedule options: plain attributes (defaults = what the measurements of rounds 1-3 chose; probes and
+        #      `bench.py --opt name=value` set them; the library reads no environment variable for any of them) ------------
         self.multi_stream = True
-        # Folding the BatchNorm statistics inside the consumer kernels (csrc/common.hpp BnFold) removes the 15
-        # finalize launches from the forward chain, but every workgroup then re-reads the partials: measured on
-        # MI355X it costs each consumer what the launch saved (depthwise block 1: 40 -> 49 us) — off by default.
-        self.fold_bn = False     # fold EVERY BatchNorm into its consumers (slower: big layers have thousands of partials)
+        self.fold_bn = False      # fold EVERY BatchNorm into its consumers (slower: big layers have thousands of partials)
+        # fold only the BatchNorms with at most this many statistics partials per channel into their depthwise / pointwise
+        # consumers (one finalize launch less on the chain each; a folded stem BatchNorm - 1024 partials - costs block 1's
+        # depthwise what the launch saves)
+        self.fold_np_max = 512
+        self.fold_np_max_pw = 32
+        self.fold_bf16 = True     # the same for the bf16 step
+        # bf16 path: head convolutions on the fp32 kernels from an fp32 feature copy ("f32": measured faster at every size
+        # tried, and no second rounding of the head operands) or on the bf16 MFMA kernel from a channels-last bf16 copy
+        # ("bf16", inference only)
+        self.bf16_heads = "f32"
         # 0: every block's weight gradients on the wgrad stream; 1: odd blocks on the heads stream (idle once the head
         # gradients are done); 2: three ways, the third on a stream of its own
-        self.split_wgrad = int(os.environ.get("MSL_WGRAD_SPLIT", "1"))
-        self.extra = {}
-        self.early_pw_bww = os.environ.get("MSL_EARLY_PW_BWW", "0") == "1"
-        self.fold_bf16 = os.environ.get("MSL_BF16_FOLD", "1") == "1"
-        # bf16 path: head convolutions on the fp32 kernels from an fp32 feature copy ("f32", default: measured faster at every
-        # size tried - 46 vs 32 us per scale at 192^3 x 2, 100 vs 28 us at 16^3 x 4 - and no second rounding of the head
-        # operands) or on the bf16 MFMA kernel from a channels-last bf16 copy ("bf16", inference only)
-        self.bf16_heads = os.environ.get("MSL_BF16_HEADS", "f32")  # bf16 step: BatchNorm finalize folded into consumers
-        # an event record costs the chain ~6 us (the next kernel waits for the barrier packet): the weight gradients of
-        # several blocks can share one record, at the price of starting up to that many blocks later
-        e = os.environ.get("MSL_WGRAD_RECORD_AT")
-        self.wgrad_record_at = None if e is None else {int(v) for v in e.split(",") if v.strip()}
-        # the weight gradients of block i are enqueued after the chain launches of block i - wgrad_lag (host enqueue order
-        # only; on the device they wait for their events): a larger lag keeps the dependency chain's queue ahead of the GPU
-        self.wgrad_lag = int(os.environ.get("MSL_WGRAD_LAG", "1"))
-        # pointwise weight gradients of the tail blocks (<= 4096 positions per batch: 64-256 workgroups of a few chunks,
-        # launches that are all latency) in ONE launch, issued when the last of them has its dL/dy (single process only:
-        # a data-parallel step completes block 7's gradient bucket before block 4 is reached)
-        self.batch_tail_pw = os.environ.get("MSL_PW_BWW_BATCH", "1") == "1"
-        # (dL/dlocs, dL/dscores) -> the zero-haloed head gradient images of ALL scales in one launch on the chain, in front of
-        # the fork to the heads stream (was one ~6 us launch per scale, two of them on the heads stream)
-        self.batch_head_gpack = os.environ.get("MSL_HEAD_GPACK_BATCH", "1") == "1"
-        # NaN-flag reset + head weight packing at the start of a forward pass on the heads stream instead of the chain
-        self.prologue_on_side = os.environ.get("MSL_PROLOGUE_ON_SIDE", "1") == "1"
-        e = os.environ.get("MSL_WGRAD_ON_HEADS")
-        self.wgrad_on_heads = None if e is None else {int(v) for v in e.split(",") if v.strip()}
-        # default: fold only the BatchNorms with at most this many partials per channel (MSL_FOLD_NP_MAX).  Round 2 A/B at
-        # 128^3 x 4 (tools/probes/r02_fold.sh): thresholds 32 / 64 / 512 / 65536 give the same step time (0.928-0.935 ms) but
-        # the depthwise forwards take 56 / 60 / 65 / 69 us back to back - a folded stem BatchNorm (1024 partials) costs block
-        # 1's depthwise 4.5 us, what the finalize launch it saves costs the chain.  64 keeps the kernels near their roofline.
-        self.fold_np_max = int(os.environ.get("MSL_FOLD_NP_MAX", "512"))
-        self.fold_np_max_pw = int(os.environ.get("MSL_FOLD_NP_MAX_PW", "32"))
-        self.fuse_stem = True    # block-1 / stem backward without materialising dL/d(stem activation)
+        self.split_wgrad = 1
+        self.wgrad_on_heads = None   # explicit set of blocks whose weight gradients go to the heads stream (probes)
+        # an event record costs the chain ~6 us: the weight gradients of several blocks can share one (a set of block indices)
+        # at the price of starting later - measured slower every time (the side streams are as critical as the chain)
+        self.wgrad_record_at = None
+        self.early_pw_bww = False    # start the pointwise weight gradient when dL/dy is final (one more record: slower)
+        # the weight gradients of block i are enqueued after the chain launches of block i - wgrad_lag (host order only)
+        self.wgrad_lag = 1
+        self.batch_tail_pw = True    # pointwise weight gradients of the tail blocks in ONE launch (single process only)
+        self.batch_head_gpack = True  # head-gradient images of all scales in one launch
+        self.prologue_on_side = True  # NaN-flag reset + head weight packing on the heads stream instead of the chain
+        self.side_stream_priority = 0
+        self.fuse_stem = True     # block-1 / stem backward without materialising dL/d(stem activation)
         self.channel_link = True  # per-channel backward links of the tail blocks in one launch each (csrc/chanlink.hip)
         self.fuse_pw_bwd = True   # whole pointwise backward of the big early block in one pass (csrc/pwfused.hip)
+        self.extra = {}
         self.side = {}
         self.arena = None
         self.plans = {}
@@ -336,7 +326,7 @@ class Engine:
         """(heads, wgrad) torch streams for ``device`` (created once)."""
         key = (device.type, device.index)
         if key not in self.side:
-            pr = int(os.environ.get("MSL_SIDE_STREAM_PRIORITY", "0"))
+            pr = self.side_stream_priority
             # (restricting the side streams to a CU subset with hipExtStreamCreateWithCUMask was measured 8-9 % slower for
             # every mask - half, quarter, three quarters of the chip - so they are ordinary streams)
             self.side[key] = (torch.cuda.Stream(device=device, priority=pr), torch.cuda.Stream(device=device, priority=pr))
@@ -345,7 +335,7 @@ class Engine:
     def extra_stream(self, device):
         key = (device.type, device.index)
         if key not in self.extra:
-            self.extra[key] = torch.cuda.Stream(device=device, priority=int(os.environ.get("MSL_SIDE_STREAM_PRIORITY", "0")))
+            self.extra[key] = torch.cuda.Stream(device=device, priority=self.side_stream_priority)
         return self.extra[key]
 
     @staticmethod

@@ -37,16 +37,19 @@ class FusedTrainer:
         self._stream = None        # the step runs on its own stream (graph capture needs a non-default one)
         # block after which the target matching is enqueued (a block that forks the heads stream anyway shares its event;
         # A/B after block 4 / 5 at the end of round 3: equal within noise)
-        self.match_after = int(os.environ.get("MSL_MATCH_AFTER", "4"))
+        self.match_after = 4
+        # which stream carries the overlapped gradient collectives: "heads" | "wgrad" | "own" (see _reducer)
+        self.dp_comm_stream = "heads"
+        self.main_stream_priority = -1  # the dependency chain must not queue behind the side streams' bulk work
 
     def _reducer(self, arena):
         if self.reducer is None or self.reducer.arena is not arena:
             self.reducer = GradBucketReducer(arena, self.n_buckets, self.group)
-            # which stream carries the overlapped collectives (MSL_DP_COMM_STREAM=heads|wgrad|own).  A fifth HIP stream
+            # which stream carries the overlapped collectives (self.dp_comm_stream = heads | wgrad | own).  A fifth HIP stream
             # per process is not free on this runtime: in the one-rank rehearsal a stream of their own costs 3.9 % of the
             # step, the wgrad stream 3.0 %, the heads stream 0.7 % (it is idle between the head gradients and the odd
             # blocks' weight gradients, and a bucket has to wait for that stream's work anyway)
-            which = os.environ.get("MSL_DP_COMM_STREAM", "heads")
+            which = self.dp_comm_stream
             eng = self.model._engine
             if self.reducer.comm_stream is not None and eng.multi_stream and which in ("heads", "wgrad"):
                 sH, sW = eng.side_streams(arena.grad.device)
@@ -160,7 +163,7 @@ class FusedTrainer:
         red = self._reducer(arena)
         if self._stream is None or self._stream.device != dev:
             # high priority: the dependency chain must not queue behind the bulk weight-gradient work of the side streams
-            self._stream = torch.cuda.Stream(device=dev, priority=int(os.environ.get("MSL_MAIN_STREAM_PRIORITY", "-1")))
+            self._stream = torch.cuda.Stream(device=dev, priority=self.main_stream_priority)
         caller = torch.cuda.current_stream(dev)
         unfenced = (not fence) and resident and not sync and self.use_programs  # decided for good once the program is known
         if not unfenced:

@@ -560,13 +560,12 @@ def test_bf16_inference_against_the_fp32_oracle(size, n):
         assert hit >= 0.9 * len(ob[i])
 
 
-def test_bf16_inference_with_the_bf16_head_kernel(monkeypatch):
-    """MSL_BF16_HEADS=bf16 keeps the head convolutions on the bf16 MFMA kernel (channels-last bf16 feature copy) instead of
-    the default fp32 head kernels: same tolerances against the fp32 oracle."""
-    monkeypatch.setenv("MSL_BF16_HEADS", "bf16")
+def test_bf16_inference_with_the_bf16_head_kernel():
+    """``Engine.bf16_heads = "bf16"`` keeps the head convolutions on the bf16 MFMA kernel (channels-last bf16 feature copy)
+    instead of the default fp32 head kernels: same tolerances against the fp32 oracle."""
     size, n = (64, 64, 64), 2
     m, om = _models(size)
-    assert m._engine.bf16_heads == "bf16"
+    m._engine.bf16_heads = "bf16"
     x = detinit.make_volume_batch(9, n, 1, size)
     with torch.no_grad():
         ol, osc = om(x)

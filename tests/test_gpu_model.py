@@ -866,15 +866,14 @@ def test_bench_line_contract(dtype):
     ms_per_step / higher_is_better / scaling / vs_baseline / dtype / data / config.workload, a roofline object (bound, achieved,
     peak, unit, frac, traffic + its source, the rocprof-based fraction with its profile tag, the three accountings of the
     seven-layer depthwise aggregate under fixed keys), a cpu_baseline object (value, unit, cores, kind, sample) and the
-    MSL_* knobs that were set."""
+    schedule options that were set (`--opt`)."""
     import json
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MSL_FOLD_NP_MAX="64")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-steps", "1", "--dtype", dtype],
-                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "12", "--warmup", "3", "--cpu-steps", "1", "--dtype", dtype,
+                        "--opt", "fold_np_max=64"], cwd=root, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, lines
@@ -897,7 +896,7 @@ def test_bench_line_contract(dtype):
     assert {"in_step_event_pairs", "back_to_back", "rocprof_kernel_trace", "algorithmic_bytes"} <= set(agg)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "volumes/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
-    assert d["knobs"].get("MSL_FOLD_NP_MAX") == "64"
+    assert d["knobs"].get("fold_np_max") == "64"
 
 
 # ------------------------------------------------------------------------------------------------- three classes

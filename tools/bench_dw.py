@@ -25,4 +25,4 @@ for rep in range(3):
     torch.cuda.synchronize()
     t = sorted(a.elapsed_time(b) for a, b in evs[10:])
     med = t[len(t) // 2]
-    print(f"SLAB={os.environ.get('MSL_DW_STREAM_SLAB', 'default')} median {med*1e3:.1f} us  min {t[0]*1e3:.1f} us  -> {alg/med/1e6:.0f} GB/s algorithmic ({alg/med/1e6/8000:.3f} of 8 TB/s)")
+    print(f"median {med*1e3:.1f} us  min {t[0]*1e3:.1f} us  -> {alg/med/1e6:.0f} GB/s algorithmic ({alg/med/1e6/8000:.3f} of 8 TB/s)")
