@@ -41,8 +41,11 @@ def parse():
     ap.add_argument("--mode", choices=["train", "infer"], default="train",
                     help="train: the headline metric (training volumes/s, 128^3 x 4).  infer: BASELINE configs[3] - predict_step "
                          "(eval forward + decode + 3-D NMS) at 192^3 x 2, volumes/s + kept boxes/s + mAP on synthetic cases")
-    ap.add_argument("--train-steps", type=int, default=300, help="infer mode: optimisation steps before the timed inference "
-                    "(random-init weights never see a cube otherwise; outside the timed region)")
+    ap.add_argument("--train-steps", type=int, default=3, help="infer mode: optimisation steps before the timed inference, outside "
+                    "the timed region.  A few steps move the running statistics off their initial values and leave the foreground "
+                    "scores near 0.5: every image then reaches the 10*top_k candidate cap, i.e. the NMS kernels do their maximum "
+                    "work (a longer run of the reference's live loss first drives every prior to background - 2500 steps: one "
+                    "placeholder box per volume, no NMS work at all)")
     ap.add_argument("--map-cases", type=int, default=8, help="infer mode: synthetic cases scored for mAP@0.1 / 0.5")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="set a schedule option of the engine / trainer / launch-program replayer for A/B runs, e.g. --opt "
