@@ -159,6 +159,13 @@ int msl_dwconv_s2_bwd_bnreduce_bww(const float* dy, const float* w, const float*
                                    const float* bn_shift, const float* bn_mean, const float* bn_invstd,
                                    double* bn_partials, double* w_partials, float* w_taps_t, int N, int C, int D, int H,
                                    int W, void* stream);
+/* the same pass when the input gradient is a tensor of its own (every stride-2 block but the one behind a fused stem): also
+ * writes g_in (N,C,D,H,W) = dL/d relu(bn(y_prev)) (accumulate != 0: on top of the heads' share already there) - one launch
+ * instead of msl_dwconv_bwd_data_bnreduce + msl_dwconv_bwd_weight; partial counts as msl_dwconv_s2_bwd_bnreduce_bww_num_partials */
+int msl_dwconv_s2_bwd_data_bnreduce_bww(const float* dy, const float* w, float* g_in, const float* y_prev,
+                                        const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                        const float* bn_invstd, double* bn_partials, double* w_partials, int N, int C, int D,
+                                        int H, int W, int accumulate, void* stream);
 int msl_dwconv_bwd_weight_finalize(const double* w_partials, int num_partials, float* dw, int C, void* stream);
 int msl_dwconv_bwd_weight_num_partials(int N, int C, int D, int H, int W, int stride);
 int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale, const float* in_shift, float* dw,

@@ -41,6 +41,7 @@ _SIGNATURES = {
     "msl_stem_conv_bwd_weight_fused": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_s2_bwd_bnreduce_bww_num_partials": (_I, [_I, _I, _I, _I, _I]),
     "msl_dwconv_s2_bwd_bnreduce_bww": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_s2_bwd_data_bnreduce_bww": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_finalize": (_I, [_P, _I, _P, _I, _P]),
     "msl_dwconv_fwd_num_partials": (_I, [_I, _I, _I, _I, _I, _I]),
     "msl_dwconv_fwd_variant": (_I, [_I, _I, _I, _I, _I, _I]),

@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
     const T* __restrict__ dy, const float* __restrict__ w, int C, int D, int H, int W, int OD, int OH, int OW,
     const T* __restrict__ y_prev, const float* __restrict__ bn_scale, const float* __restrict__ bn_shift,
     const float* __restrict__ bn_mean, const float* __restrict__ bn_invstd, double* __restrict__ bn_partials,
-    double* __restrict__ w_partials, float* __restrict__ w_taps_t) {
+    double* __restrict__ w_partials, float* __restrict__ w_taps_t, T* __restrict__ g_in, int accumulate) {
   __shared__ float red[4][32];
   const int nc = blockIdx.y, c = nc % C;
   // tap-major copy of the weights, (27, C): the consumer kernel then fetches 8 channels of one tap with one scalar load
@@ -423,7 +423,17 @@ __global__ __launch_bounds__(256) void dw_s2_bwd_reduce_bww_kernel(
             aw[kb + 2] = fmaf(av[1], d0, fmaf(av[3], d1, aw[kb + 2]));
           }
         }
-        const float ga[4] = {o0, o1, o2, o3};
+        float ga[4] = {o0, o1, o2, o3};
+        if (g_in) {  // (block 2+: the input gradient is a tensor of its own; with `accumulate` the heads' share is added first)
+          T* gp = g_in + (size_t)nc * D * H * W + (okp[pd][ph] ? ((size_t)(2 * a + pd) * H + 2 * b + ph) * W + iw0 : 0);
+          if (accumulate) {
+            const float4 old = msl::ld4(gp);
+            ga[0] += old.x; ga[1] += old.y; ga[2] += old.z; ga[3] += old.w;
+          }
+          const float4 gs = msl::as_stored(gp, make_float4(ga[0], ga[1], ga[2], ga[3]));
+          if (okp[pd][ph]) msl::st4(gp, gs);
+          ga[0] = gs.x; ga[1] = gs.y; ga[2] = gs.z; ga[3] = gs.w;
+        }
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const float gm = av[k] > 0.f ? ga[k] : 0.f;  // av > 0  <=>  inside the volume and relu(bn(y)) > 0
@@ -615,7 +625,26 @@ int msl_dwconv_s2_bwd_bnreduce_bww(const float* dy, const float* w, const float*
   const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
   hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
-                     OH, OW, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, bn_partials, w_partials, w_taps_t);
+                     OH, OW, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, bn_partials, w_partials, w_taps_t, (float*)nullptr, 0);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// The same pass for a stride-2 depthwise layer whose input gradient IS a tensor (any block but the one behind a fused stem):
+// additionally writes g_in (N,C,D,H,W) = dL/d relu(bn(y_prev)) (accumulate != 0: adds the heads' share already in g_in, and the
+// BatchNorm sums are those of the total).  One launch instead of msl_dwconv_bwd_data_bnreduce + msl_dwconv_bwd_weight: the
+// weight gradient pairs each activation with the very dL/dz values the transposed convolution multiplies with the taps.
+int msl_dwconv_s2_bwd_data_bnreduce_bww(const float* dy, const float* w, float* g_in, const float* y_prev,
+                                        const float* bn_scale, const float* bn_shift, const float* bn_mean,
+                                        const float* bn_invstd, double* bn_partials, double* w_partials, int N, int C, int D,
+                                        int H, int W, int accumulate, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || !g_in) return MSL_ERR_ARG;
+  if (W % 4 != 0) return MSL_ERR_UNSUPPORTED;
+  const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
+  dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
+  hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
+                     OH, OW, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, bn_partials, w_partials, (float*)nullptr, g_in,
+                     accumulate);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -631,7 +660,7 @@ int msl_dwconv_s2_bwd_bnreduce_bww_bf16(const void* dy, const float* w, const vo
   typedef msl::su16 u16;
   hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w, C,
                      D, H, W, OD, OH, OW, (const u16*)y_prev, bn_vec, bn_vec + C, bn_vec + 2 * C, bn_vec + 3 * C, bn_partials,
-                     w_partials, w_taps_t);
+                     w_partials, w_taps_t, (u16*)nullptr, 0);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

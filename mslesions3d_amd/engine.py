@@ -223,6 +223,14 @@ class Plan:
                 if nf > 0:
                     self.pw_fused[i] = (torch.empty(nf * specs[i]["cin"] * specs[i]["cout"], **f32),
                                         torch.empty(2 * specs[i]["cin"] * nf, dtype=torch.float64, device=device), nf)
+            # big stride-2 blocks whose depthwise weight gradient comes with their bwd-data pass: fp64 partials [Cin*27][NP]
+            self.dw_fused_part = {}
+            for i in range(2, len(specs)):
+                pd, ph, pw = self.dims[i - 1]
+                if specs[i]["stride"][0] == 2 and N * pd * ph * pw > 65536:
+                    npw = L.msl_dwconv_s2_bwd_bnreduce_bww_num_partials(N, specs[i]["cin"], pd, ph, pw)
+                    if npw > 0 and 2 * specs[i]["cin"] * npw <= self.partials.numel():
+                        self.dw_fused_part[i] = (torch.empty(specs[i]["cin"] * 27 * npw, dtype=torch.float64, device=device), npw)
             self.head_nslabs = {f: L.msl_head_conv_bwd_weight_nslabs(N, specs[f]["cout"], *self.dims[f], ncls) for f in self.feat_ids}
             self.stem_nslabs = L.msl_stem_conv_bwd_weight_nslabs(N, *self.in_dims, *specs[0]["stride"])
             self.grad_tables = {}
@@ -242,6 +250,7 @@ class Plan:
         self.generation = 0
         self.dw_in_link = set()  # blocks whose depthwise weight gradient a channel link writes (no partials to fold)
         self.pw_fused_used = set()  # blocks whose pointwise weight-gradient slabs came with the fused pointwise backward
+        self.dw_fused_used = set()  # blocks whose depthwise weight-gradient partials came with their bwd-data pass
 
 
 class Engine:
@@ -285,6 +294,7 @@ class Engine:
         self.fuse_stem = True     # block-1 / stem backward without materialising dL/d(stem activation)
         self.channel_link = True  # per-channel backward links of the tail blocks in one launch each (csrc/chanlink.hip)
         self.fuse_pw_bwd = True   # whole pointwise backward of the big early block in one pass (csrc/pwfused.hip)
+        self.fuse_dw_bww = True   # depthwise weight gradient of a big stride-2 block inside its bwd-data pass
         self.extra = {}
         self.side = {}
         self.arena = None
@@ -1286,6 +1296,7 @@ class Engine:
                 self._wait(st, pl.events[f"head_done{i - 1}"])
             # big producer layers: emit the BatchNorm-backward partials of y_{i-1} while its gradient is in registers
             ev_red = None
+            dw_fused = False
             if link:
                 prev = "base.features.0.1" if i == 1 else f"base.features.{i - 1}.bn2"
                 self._k(f"link{i}", "msl_block_bwd_channel_link", ptr(pl.g_z[i]), ptr(pl.z[i]), ptr(pl.bn_z[i]),
@@ -1305,6 +1316,18 @@ class Engine:
                         ptr(vp[0]), ptr(vp[1]), ptr(vp[2]), ptr(vp[3]), ptr(pl.partials), ptr(pl.partials_wf), ptr(pl.w1_taps_t),
                         N, 32, pd, ph, pw, st)
                 pre_np = pl.fused_stem_np
+            elif np_red > 0 and self.fuse_dw_bww and i in pl.dw_fused_part:
+                # big stride-2 producer layer: bwd-data, the BatchNorm-backward sums of y_{i-1} AND this block's depthwise
+                # weight gradient in one pass over (dL/dz_i, y_{i-1}) - the weight-gradient launch on the side stream (the same
+                # 38 MB read again, 35 us beside the chain at block 2) disappears
+                vp = pl.bn_y[i - 1]
+                part_w, np_w = pl.dw_fused_part[i]
+                self._k(f"dw_bwd{i}", "msl_dwconv_s2_bwd_data_bnreduce_bww", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight),
+                        ptr(pl.g_y[i - 1]), ptr(pl.y[i - 1]), ptr(vp[0]), ptr(vp[1]), ptr(vp[2]), ptr(vp[3]), ptr(pl.partials),
+                        ptr(part_w), N, sp["cin"], pd, ph, pw, accumulate, st)
+                pre_np = np_w
+                dw_fused = True
+                pl.dw_fused_used.add(i)
             elif np_red > 0 and 2 * sp["cin"] * np_red <= pl.partials.numel():
                 vp = pl.bn_y[i - 1]
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data_bnreduce", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight),
@@ -1314,8 +1337,9 @@ class Engine:
             else:
                 self._k(f"dw_bwd{i}", "msl_dwconv_bwd_data", ptr(pl.g_z[i]), ptr(feats[i].conv1.weight), ptr(pl.g_y[i - 1]),
                         N, sp["cin"], pd, ph, pw, s, accumulate, st)
-            def wgrads(ev_dz, i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name, fused_stem=fused_stem or link_bww,
-                       ev_red=ev_red, ev_dy=ev_dy, idle_sink=idle_sink, pw_fused=pw_fused):
+            def wgrads(ev_dz, i=i, sp=sp, S=S, pd=pd, ph=ph, pw=pw, s=s, name=name,
+                       fused_stem=fused_stem or link_bww or dw_fused, ev_red=ev_red, ev_dy=ev_dy, idle_sink=idle_sink,
+                       pw_fused=pw_fused):
                 # split_wgrad: the heads stream is idle once the head gradients are done - odd blocks go there
                 streams = [stW, stH, stX]
                 sX = streams[i % (self.split_wgrad + 1)] if ms else st
@@ -1450,6 +1474,9 @@ class Engine:
                 if want(name + ".conv1.weight") and i not in getattr(pl, "dw_in_link", ()):  # (a channel link wrote it)
                     if i == 1 and fused:
                         rows.append((1, pl.partials_wf, gv[name + ".conv1.weight"], None, pl.fused_stem_np, specs[i]["cin"] * 27, 0, 0, 0, 0))
+                    elif i in getattr(pl, "dw_fused_used", ()):
+                        part_w, np_w = pl.dw_fused_part[i]
+                        rows.append((1, part_w, gv[name + ".conv1.weight"], None, np_w, specs[i]["cin"] * 27, 0, 0, 0, 0))
                     else:
                         rows.append((1, pl.dw_part[i], gv[name + ".conv1.weight"], None, pl.dw_np[i], specs[i]["cin"] * 27, 0, 0, 0, 0))
             if want("base.features.0.0.weight"):

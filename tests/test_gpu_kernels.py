@@ -872,3 +872,43 @@ def test_pwconv_bwd_fused_matches_autograd(n, s_dims):
     _lib.call("msl_pwconv_bwd_fused", ptr(K(G)), ptr(K(y)), ptr(K(vy)), ptr(K(parts)), ynp, float(n * S), ptr(dgam), ptr(dbet),
               ptr(K(conv.weight)), ptr(K(z)), ptr(K(vz)), ptr(gz2), ptr(zpart2), ptr(slabs2), n, cin, cout, S, st())
     assert torch.equal(gz, gz2) and torch.equal(zpart, zpart2) and torch.equal(slabs, slabs2)
+
+
+# ------------------------------------------------------------------------------------------------- dw bwd-data + BN sums + dW in one pass
+@pytest.mark.parametrize("n,c,dims,acc", [(2, 16, (8, 8, 8), 0), (1, 8, (10, 14, 20), 1), (3, 4, (6, 6, 36), 0), (2, 64, (32, 32, 32), 0)])
+def test_dw_s2_bwd_data_bnreduce_bww_matches_autograd(n, c, dims, acc):
+    """msl_dwconv_s2_bwd_data_bnreduce_bww: input gradient of a stride-2 depthwise layer (+ the heads' share), the
+    BatchNorm-backward sums of the producer layer and the depthwise weight gradient in ONE pass, against torch autograd of
+    dwconv(relu(bn(y))) (mobilenet.py:44 backward; odd output extents included)."""
+    L = _lib.load()
+    D, H, W = dims
+    y = rnd(n, c, D, H, W, seed=1).requires_grad_(True)
+    bn = torch.nn.BatchNorm3d(c)
+    conv = torch.nn.Conv3d(c, c, 3, stride=2, padding=1, groups=c, bias=False)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(c, generator=torch.Generator().manual_seed(3)) + 0.5)
+        bn.bias.copy_(rnd(c, seed=4, scale=0.3))
+        conv.weight.copy_(rnd(c, 1, 3, 3, 3, seed=5, scale=0.3))
+    a = torch.relu(bn(y))
+    a.retain_grad()
+    z = conv(a)
+    dz = rnd(*z.shape, seed=6)
+    hs = rnd(*a.shape, seed=7) if acc else torch.zeros_like(a)
+    ((z * dz).sum() + (a * hs).sum()).backward()
+    mean, var = y.detach().mean(dim=(0, 2, 3, 4)), y.detach().var(dim=(0, 2, 3, 4), unbiased=False)
+    inv = 1.0 / torch.sqrt(var + bn.eps)
+    sc = (bn.weight * inv).detach()
+    vec = K(torch.stack([sc, (bn.bias - mean * sc).detach(), mean, inv]))
+    NP = L.msl_dwconv_s2_bwd_bnreduce_bww_num_partials(n, c, D, H, W)
+    assert NP > 0
+    bp = K(torch.full((2 * c * NP,), float("nan"), dtype=torch.float64))
+    wp = K(torch.full((c * 27 * NP,), float("nan"), dtype=torch.float64))
+    g_in = K(hs if acc else torch.full_like(hs, 9.0))
+    _lib.call("msl_dwconv_s2_bwd_data_bnreduce_bww", ptr(K(dz)), ptr(K(conv.weight)), ptr(g_in), ptr(K(y)), ptr(vec[0]), ptr(vec[1]),
+              ptr(vec[2]), ptr(vec[3]), ptr(bp), ptr(wp), n, c, D, H, W, acc, st())
+    close(g_in, a.grad, 1e-4, 1e-5 * float(a.grad.abs().max()), "dL/d relu(bn(y))")
+    sums = bp.view(2, c, NP).sum(-1).cpu()
+    close(sums[0], bn.bias.grad, 2e-4, 1e-5 * float(bn.bias.grad.abs().max()), "sum gm (= dbeta)")
+    close(sums[1], bn.weight.grad, 2e-4, 1e-5 * float(bn.weight.grad.abs().max()), "sum gm * xhat (= dgamma)")
+    dw = wp.view(c * 27, NP).sum(-1).float().view(c, 1, 3, 3, 3)
+    close(dw, conv.weight.grad, 2e-4, 1e-5 * float(conv.weight.grad.abs().max()), "depthwise weight gradient")
