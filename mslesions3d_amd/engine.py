@@ -295,6 +295,10 @@ class Engine:
         self.channel_link = True  # per-channel backward links of the tail blocks in one launch each (csrc/chanlink.hip)
         self.fuse_pw_bwd = True   # whole pointwise backward of the big early block in one pass (csrc/pwfused.hip)
         self.fuse_dw_bww = True   # depthwise weight gradient of a big stride-2 block inside its bwd-data pass
+        # a channel link also produces the depthwise weight gradient while it has at most this many waves per channel (with
+        # more it is bound by instruction issue; the stride-2 forms above 4 waves also spill)
+        self.link_bww_max_waves = 4
+        self.link_bww_max_waves_s1 = 4
         self.extra = {}
         self.side = {}
         self.arena = None
@@ -895,7 +899,7 @@ class Engine:
             # the per-channel link of the tail blocks in one launch, as in the fp32 step (csrc/chanlink.hip on bf16 storage)
             link_nw = L.msl_block_bwd_channel_link_supported(N, pd, ph, pw, s) if self.channel_link else 0
             link = link_nw > 0 and not fused_stem and not big_producer and i >= 2
-            link_bww = link and link_nw <= 4
+            link_bww = link and (link_nw <= self.link_bww_max_waves or (s == 1 and link_nw <= self.link_bww_max_waves_s1))
             if not link:
                 self._bn_bwd_bf16(pl.g_z[i], pl.z[i], pl.bn_z[i], name + ".bn1", N, sp["cin"], S, pl, st)
             if accumulate and (i - 1) in side_feats:
@@ -1283,7 +1287,7 @@ class Engine:
             link_nw = L.msl_block_bwd_channel_link_supported(N, pd, ph, pw, s) if self.channel_link else 0
             link = link_nw > 0 and not fused_stem and np_red <= 0 and not pw_fused
             # (with <= 4 waves per channel the link takes the depthwise weight gradient along: no launch for it below)
-            link_bww = link and link_nw <= 4
+            link_bww = link and (link_nw <= self.link_bww_max_waves or (s == 1 and link_nw <= self.link_bww_max_waves_s1))
             # a block whose pointwise weight gradient rides in the tail's batched launch (issued with the shallowest of them) and
             # whose depthwise weight gradient the link produces has nothing waiting for dL/dz_i: no event record on the chain
             idle_sink = (link_bww and i in tail and i != tail[-1]) or (pw_fused and fused_stem)
