@@ -270,8 +270,9 @@ class Engine:
         # fold only the BatchNorms with at most this many statistics partials per channel into their depthwise / pointwise
         # consumers (one finalize launch less on the chain each; a folded stem BatchNorm - 1024 partials - costs block 1's
         # depthwise what the launch saves)
-        self.fold_np_max = 512
-        self.fold_np_max_pw = 32
+        self.fold_np_max = 512     # (65536 - the stem's 1024 partials too - gains another 2 us per step but costs the roofline
+        #                             kernel, block 1's depthwise forward, 4.5 us: the launch stays)
+        self.fold_np_max_pw = 64   # block 1's depthwise layer emits 64 partials per channel: folded by its pointwise consumer
         self.fold_bf16 = True     # the same for the bf16 step
         # bf16 path: head convolutions on the fp32 kernels from an fp32 feature copy ("f32": measured faster at every size
         # tried, and no second rounding of the head operands) or on the bf16 MFMA kernel from a channels-last bf16 copy
