@@ -398,6 +398,8 @@ size_t msl_grad_reduce_entry_bytes(void);
 int msl_grad_reduce_table_set(void* host_table, int index, int first_block, int kind, const void* src, float* dst,
                               float* dst2, int nslabs, int count, long long stride, int p0, int p1, int p2);
 int msl_grad_reduce_batch(const void* table, int n_entries, int total_blocks, void* stream);
+/* the same; block_entry[total_blocks] (device) names every workgroup's table entry, so no workgroup searches the table */
+int msl_grad_reduce_batch_indexed(const void* table, int n_entries, const int* block_entry, int total_blocks, void* stream);
 /* stream fork/join (hipEvent with timing disabled): record on the producer stream, wait on the consumer stream */
 int msl_event_create(void** out);
 int msl_event_create_timed(void** out);                       /* timing-enabled event (launch-duration measurements) */

@@ -70,6 +70,7 @@ _SIGNATURES = {
     "msl_grad_reduce_entry_bytes": (_Z, []),
     "msl_grad_reduce_table_set": (_I, [_P, _I, _I, _I, _P, _P, _P, _I, _I, _Q, _I, _I, _I]),
     "msl_grad_reduce_batch": (_I, [_P, _I, _I, _P]),
+    "msl_grad_reduce_batch_indexed": (_I, [_P, _I, _P, _I, _P]),
     "msl_head_packed_weight_elems": (_Z, [_I, _I]),
     "msl_head_pack_weights": (_I, [_P, _P, _P, _P, _I, _I, _P]),
     "msl_head_pack_weights_batch": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),

@@ -72,12 +72,17 @@ __host__ __device__ __forceinline__ bool grad_reduce_few(int kind, int nslabs, i
   return kind != GR_ELEM_F64 && nslabs <= GR_FEW && count % 4 == 0 && stride % 4 == 0;
 }
 
-__global__ __launch_bounds__(256) void grad_reduce_batch_kernel(const GradReduceEntry* __restrict__ table, int n_entries) {
+__global__ __launch_bounds__(256) void grad_reduce_batch_kernel(const GradReduceEntry* __restrict__ table, int n_entries,
+                                                                const int* __restrict__ block_entry) {
   __shared__ float lds[8 * 33];
   __shared__ double ldsd[8 * 33];
   int e = 0;
-  for (int k = 1; k < n_entries; ++k)
-    if ((int)blockIdx.x >= table[k].first_block) e = k;
+  if (block_entry) {
+    e = block_entry[blockIdx.x];  // one load instead of a walk over up to 64 first_block fields (dependent scalar loads)
+  } else {
+    for (int k = 1; k < n_entries; ++k)
+      if ((int)blockIdx.x >= table[k].first_block) e = k;
+  }
   const GradReduceEntry en = table[e];
   const int blk = blockIdx.x - en.first_block;
   const int li = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -236,7 +241,17 @@ int msl_grad_reduce_table_set(void* host_table, int index, int first_block, int 
 int msl_grad_reduce_batch(const void* table, int n_entries, int total_blocks, void* stream) {
   if (!table || n_entries <= 0 || n_entries > 64 || total_blocks <= 0) return MSL_ERR_ARG;
   hipLaunchKernelGGL(grad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
-                     (const GradReduceEntry*)table, n_entries);
+                     (const GradReduceEntry*)table, n_entries, (const int*)nullptr);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// the same with a device array block_entry[total_blocks] = table entry of every workgroup (the caller knows it from the counts
+// msl_grad_reduce_table_set returned): the workgroups then do not search the table
+int msl_grad_reduce_batch_indexed(const void* table, int n_entries, const int* block_entry, int total_blocks, void* stream) {
+  if (!table || !block_entry || n_entries <= 0 || n_entries > 64 || total_blocks <= 0) return MSL_ERR_ARG;
+  hipLaunchKernelGGL(grad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const GradReduceEntry*)table, n_entries, block_entry);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

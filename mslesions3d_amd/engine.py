@@ -1495,17 +1495,20 @@ class Engine:
             esz = L.msl_grad_reduce_entry_bytes()
             host = (ctypes.c_ubyte * (esz * max(len(rows), 1)))()
             first = 0
+            owner = []  # table entry of every workgroup
             for k, (kind, src, dst, dst2, ns, cnt, stride, p0, p1, p2) in enumerate(rows):
                 nb = L.msl_grad_reduce_table_set(ctypes.addressof(host), k, first, kind, ptr(src), ptr(dst), ptr(dst2), ns, cnt,
                                                  stride, p0, p1, p2)
                 if nb < 0:
                     raise _lib.HipKernelError(f"msl_grad_reduce_table_set failed for entry {k} (kind {kind})")
                 first += nb
-            table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(self.arena.grad.device) if rows else None
-            ent = pl.grad_tables[tkey] = (table, len(rows), first)
-        table, n, blocks = ent
+                owner += [k] * nb
+            dev = self.arena.grad.device
+            table = torch.frombuffer(bytearray(host), dtype=torch.uint8).to(dev) if rows else None
+            ent = pl.grad_tables[tkey] = (table, len(rows), first, torch.tensor(owner, dtype=torch.int32, device=dev))
+        table, n, blocks, owner = ent
         if n:
-            self._k(f"grad_reduce:{key}", "msl_grad_reduce_batch", ptr(table), n, blocks, st)
+            self._k(f"grad_reduce:{key}", "msl_grad_reduce_batch_indexed", ptr(table), n, ptr(owner), blocks, st)
 
     def check_nan(self, pl):
         """One host sync: raise like ssd3d.py:258-261 if the forward produced NaN."""
