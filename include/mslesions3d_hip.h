@@ -402,6 +402,7 @@ int msl_grad_reduce_batch(const void* table, int n_entries, int total_blocks, vo
 int msl_grad_reduce_batch_indexed(const void* table, int n_entries, const int* block_entry, int total_blocks, void* stream);
 /* stream fork/join (hipEvent with timing disabled): record on the producer stream, wait on the consumer stream */
 int msl_event_create(void** out);
+int msl_event_create_device(void** out);                      /* orders streams of ONE device only (hipEventDisableSystemFence): never for host waits or other devices */
 int msl_event_create_timed(void** out);                       /* timing-enabled event (launch-duration measurements) */
 int msl_event_elapsed_ms(void* start, void* stop, float* out_ms);
 int msl_event_destroy(void* ev);

@@ -135,6 +135,7 @@ _SIGNATURES = {
     "msl_run_program_mt": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
     "msl_event_create": (_I, [_P]),
+    "msl_event_create_device": (_I, [_P]),
     "msl_event_create_timed": (_I, [_P]),
     "msl_event_elapsed_ms": (_I, [_P, _P, _P]),
     "msl_event_destroy": (_I, [_P]),
@@ -171,10 +172,22 @@ def exported_names():
     return sorted(_SIGNATURES.keys())
 
 
-def new_event():
-    """A hipEvent (timing disabled) as an opaque integer handle."""
+# True: the fork / join events inside a launch program are created with hipEventDisableSystemFence - they order streams of
+# one GPU, where the kernel packets' own agent-scope fences already make the data visible; the system-scope release a default
+# event adds at every record cost the recording stream 4-7 us each (15 records on the dependency chain of a training step:
+# 0.718 -> 0.688 ms, same-box A/B).  Host-visible results still pass a system-scope release: the caller's stream waits for
+# the chain through an ordinary torch event / stream synchronize.  tests/test_gpu_model.py::test_device_scope_events_*
+DEVICE_SCOPE_EVENTS = True
+
+
+def new_event(device_only=False):
+    """A hipEvent (timing disabled) as an opaque integer handle.  ``device_only``: the event only ever orders streams of
+    this GPU (fork / join inside a launch program) and may be created without the system-scope fence."""
     out = ctypes.c_void_p()
-    check(load().msl_event_create(ctypes.byref(out)), "msl_event_create")
+    if device_only and DEVICE_SCOPE_EVENTS:
+        check(load().msl_event_create_device(ctypes.byref(out)), "msl_event_create_device")
+    else:
+        check(load().msl_event_create(ctypes.byref(out)), "msl_event_create")
     return out.value
 
 

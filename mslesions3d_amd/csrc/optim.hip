@@ -280,6 +280,17 @@ int msl_event_create(void** out) {
   *out = (void*)ev;
   return MSL_OK;
 }
+// An event that orders streams of ONE device only: no system-scope release / acquire at the record (hip_runtime_api.h,
+// hipEventDisableSystemFence: "device memory may not be visible to the host and other devices").  Kernel packets keep
+// their own agent-scope fences, which is what a consumer on another stream of the same GPU needs.  Never hand such an
+// event to the host (hipEventSynchronize), to a copy engine moving data to the host, or to another device's stream.
+int msl_event_create_device(void** out) {
+  hipEvent_t ev;
+  hipError_t e = hipEventCreateWithFlags(&ev, hipEventDisableTiming | hipEventDisableSystemFence);
+  if (e != hipSuccess) return (int)e;
+  *out = (void*)ev;
+  return MSL_OK;
+}
 int msl_event_create_timed(void** out) {
   hipEvent_t ev;
   hipError_t e = hipEventCreate(&ev);

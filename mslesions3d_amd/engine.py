@@ -355,9 +355,12 @@ class Engine:
 
     @staticmethod
     def _event(pl, name):
+        """The plan's event ``name``.  Events that only order this GPU's own streams are created without the
+        system-scope fence when ``_lib.DEVICE_SCOPE_EVENTS`` is set; the ``bucket_*`` events, which a communication
+        stream (RCCL: peer-to-peer traffic) waits for, always keep it."""
         ev = pl.events.get(name)
         if ev is None:
-            ev = pl.events[name] = _lib.new_event()
+            ev = pl.events[name] = _lib.new_event(device_only=not name.startswith("bucket_"))
         return ev
 
     @classmethod
