@@ -403,6 +403,13 @@ int msl_grad_reduce_batch_indexed(const void* table, int n_entries, const int* b
 /* stream fork/join (hipEvent with timing disabled): record on the producer stream, wait on the consumer stream */
 int msl_event_create(void** out);
 int msl_event_create_device(void** out);                      /* orders streams of ONE device only (hipEventDisableSystemFence): never for host waits or other devices */
+/* Fork without a record packet: the (skip + 1)-th kernel launch the calling THREAD issues from now on completes `ev`
+ * (stopEvent of hipExtLaunchKernel) exactly as if msl_event_record(ev, <that launch's stream>) followed it.
+ * msl_thread_launch_count(): kernel launches issued by the calling thread so far (launches per entry point = difference
+ * around a call); msl_stop_event_pending(): 1 while an armed event has not met its launch. */
+int msl_arm_stop_event(void* ev, int skip);
+int msl_stop_event_pending(void);
+int msl_thread_launch_count(void);      /* not an error code: the count, modulo 2^31 */
 int msl_event_create_timed(void** out);                       /* timing-enabled event (launch-duration measurements) */
 int msl_event_elapsed_ms(void* start, void* stop, float* out_ms);
 int msl_event_destroy(void* ev);

@@ -136,6 +136,9 @@ _SIGNATURES = {
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
     "msl_event_create": (_I, [_P]),
     "msl_event_create_device": (_I, [_P]),
+    "msl_arm_stop_event": (_I, [_P, _I]),
+    "msl_stop_event_pending": (_I, []),
+    "msl_thread_launch_count": (_I, []),
     "msl_event_create_timed": (_I, [_P]),
     "msl_event_elapsed_ms": (_I, [_P, _P, _P]),
     "msl_event_destroy": (_I, [_P]),
@@ -216,6 +219,41 @@ def _entry_stream(name, args):
     return args[-1]
 
 
+STOP_EVENT_FORKS = True  # compile_program: launch + msl_event_record on the same stream -> launch carrying a stop event
+
+
+def _fuse_stop_events(prog, timed_tags):
+    """-> [(fn, args, tag, stream)]: an ``msl_event_record(ev, s)`` whose predecessor on stream ``s`` is an entry point
+    that launched k >= 1 kernels becomes ``msl_arm_stop_event(ev, k - 1)`` in FRONT of that entry (the event then completes
+    with the entry's last kernel: same meaning, no record packet on the stream - csrc/common.hpp, MSL_LAUNCH).  Only with
+    launch counts from the recorder (Program.nl), never across a Python hook, never for timed launches."""
+    nl = getattr(prog, "nl", None)
+    fuse = STOP_EVENT_FORKS and nl is not None and len(nl) == len(prog)
+    arm = getattr(load(), "msl_arm_stop_event")
+    out, last = [], {}  # last[stream] = [entry, launches] of the newest entry on that stream if a record may fuse with it
+    for k, (fn, args, tag) in enumerate(prog):
+        if fn is None:
+            out.append([None, (fn, args, tag, None)])
+            last.clear()
+            continue
+        name = fn.__name__
+        stream = _entry_stream(name, args)
+        if name == "msl_event_record" and fuse and last.get(stream) is not None:
+            item, launches = last.pop(stream)
+            item[0] = (arm, (args[0], launches - 1), "stop_event", stream)
+            continue
+        item = [None, (fn, args, tag, stream)]
+        out.append(item)
+        launchy = name not in ("msl_event_record", "msl_stream_wait_event", "msl_arm_stop_event")
+        last[stream] = [item, nl[k]] if (fuse and launchy and nl[k] >= 1 and tag not in timed_tags) else None
+    flat = []
+    for pre, ent in out:
+        if pre is not None:
+            flat.append(pre)
+        flat.append(ent)
+    return flat
+
+
 def compile_program(prog, timed_tags=(), main_stream=None, device=0):
     """Recorded program -> list of segments: ("native", fn_ids, slots, n, tags, lanes, wait_for) runs in ONE foreign call
     through the generated trampolines (csrc/program_runner.hip); ("hook", callable) are the Python callbacks in between;
@@ -246,13 +284,13 @@ def compile_program(prog, timed_tags=(), main_stream=None, device=0):
         lanes.append(lane)
         waits.append(wait)
 
-    for fn, args, tag in prog:
+    armed = None
+    for fn, args, tag, stream in _fuse_stop_events(prog, timed_tags):
         if fn is None:
             flush()
             segs.append(("hook", args))
             continue
         name = fn.__name__
-        stream = _entry_stream(name, args)
         lane = 0 if (main_stream is None or stream == main_stream) else 1
         timed = tag in timed_tags
         if timed:  # event record / launch / event record back to back inside the native segment
@@ -273,10 +311,16 @@ def compile_program(prog, timed_tags=(), main_stream=None, device=0):
         push(fid, row, tag, lane, wait)
         if name == "msl_event_record":
             last_record[args[0]] = len(ids) - 1
+        elif name == "msl_arm_stop_event":
+            armed = args[0]
+        elif armed is not None:  # the entry the stop event rides on: a wait for the event may be issued once this one is
+            last_record[armed] = len(ids) - 1
+            armed = None
         if timed:
             push(rec, [0, _slot(stream, _P)], "event", lane)
     flush()
-    return {"segments": segs, "patches": patches}
+    return {"segments": segs, "patches": patches,
+            "stop_event_forks": sum(1 for seg in segs if seg[0] == "native" for t in seg[4] if t == "stop_event")}
 
 
 def new_timed_event():
@@ -338,9 +382,19 @@ def check(code, what):
 _recorder = None
 
 
+class Program(list):
+    """A recorded launch program: (fn, args, tag) entries ((None, callable, tag) = Python hook) plus, per entry, the
+    number of kernels the call launched (``nl``; compile_program needs it to turn a launch + event record into a launch
+    with a stop event)."""
+
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.nl = []
+
+
 def start_recording():
     global _recorder
-    _recorder = []
+    _recorder = Program()
 
 
 def stop_recording():
@@ -353,13 +407,20 @@ def record_hook(fn, tag=None):
     """Insert a Python callback (e.g. 'start the all-reduce of bucket k') into the program being recorded."""
     if _recorder is not None:
         _recorder.append((None, fn, tag))
+        _recorder.nl.append(0)
 
 
 def call(name, *args, tag=None):
     """Invoke an int-returning entry point and raise on a non-zero code."""
     fn = getattr(load(), name)
     if _recorder is not None:
+        count = load().msl_thread_launch_count
+        n0 = count()
+        rc = fn(*args)
         _recorder.append((fn, args, tag or name))
+        _recorder.nl.append((count() - n0) & 0x7FFFFFFF)
+        check(rc, name)
+        return
     check(fn(*args), name)
 
 

@@ -391,7 +391,7 @@ static void pw_tr_launch(const u16* z, const float* in_scale, const float* in_sh
   // several position tiles per workgroup once the launch has more than ~2 workgroups per CU (block 1: 2048 tiles)
   const int T = std::max(1, std::min(std::min(4, tiles_img), (tiles_img * mtiles * N) / 512));
   dim3 grid(msl::cdiv(tiles_img, T), mtiles, N);
-#define MSL_PT(BK_) hipLaunchKernelGGL((pw_bf16_tr_kernel<BK_, STATS, TRANS_W>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, \
+#define MSL_PT(BK_) MSL_LAUNCH((pw_bf16_tr_kernel<BK_, STATS, TRANS_W>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, \
                                        partials, M, K, S, T, fold)
   if (K % 128 == 0) MSL_PT(128);
   else if (K % 64 == 0) MSL_PT(64);
@@ -841,10 +841,10 @@ int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_sh
   dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1)
-    hipLaunchKernelGGL(dw_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)x, in_scale, in_shift, w, (u16*)y, partials,
+    MSL_LAUNCH(dw_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)x, in_scale, in_shift, w, (u16*)y, partials,
                        C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP, 0, 0);
   else
-    hipLaunchKernelGGL(dw_fwd_bf16_kernel<2>, grid, dim3(256), 0, st, (const u16*)x, in_scale, in_shift, w, (u16*)y, partials,
+    MSL_LAUNCH(dw_fwd_bf16_kernel<2>, grid, dim3(256), 0, st, (const u16*)x, in_scale, in_shift, w, (u16*)y, partials,
                        C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP, 0, 0);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -867,10 +867,10 @@ static int pw_fwd_bf16_impl(const void* z, const float* in_scale, const float* i
   }
   dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cout, PB_BM), N);
   if (partials)
-    hipLaunchKernelGGL(pw_fwd_bf16_kernel<true>, grid, dim3(256), 0, st, (const u16*)z, in_scale, in_shift, w, (u16*)y,
+    MSL_LAUNCH(pw_fwd_bf16_kernel<true>, grid, dim3(256), 0, st, (const u16*)z, in_scale, in_shift, w, (u16*)y,
                        partials, Cout, Cin, S, fold);
   else
-    hipLaunchKernelGGL(pw_fwd_bf16_kernel<false>, grid, dim3(256), 0, st, (const u16*)z, in_scale, in_shift, w, (u16*)y,
+    MSL_LAUNCH(pw_fwd_bf16_kernel<false>, grid, dim3(256), 0, st, (const u16*)z, in_scale, in_shift, w, (u16*)y,
                        partials, Cout, Cin, S, fold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -897,7 +897,7 @@ int msl_bn_relu_materialize_bf16(const void* y, const float* scale, const float*
                                  int C, int D, int H, int W, void* stream) {
   if (N <= 0 || C % 8 != 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift) return MSL_ERR_ARG;
   dim3 grid(msl::cdiv(D * H * W, 256), C / 8, N);
-  hipLaunchKernelGGL(materialize_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, plain,
+  MSL_LAUNCH(materialize_bf16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, plain,
                      (u16*)pad_cl, C, D, H, W);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -908,7 +908,7 @@ int msl_bn_relu_materialize_bf16_pad32(const void* y, const float* scale, const 
                                        int H, int W, void* stream) {
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !pad) return MSL_ERR_ARG;
   dim3 grid(msl::cdiv(D * H * W, 256), C, N);
-  hipLaunchKernelGGL(materialize_bf16_pad32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, pad, C,
+  MSL_LAUNCH(materialize_bf16_pad32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, pad, C,
                      D, H, W);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -924,7 +924,7 @@ int msl_pwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, 
     return MSL_OK;
   }
   dim3 grid(msl::cdiv(S, PB_BN), msl::cdiv(Cin, PB_BM), N);
-  hipLaunchKernelGGL((pw_fwd_bf16_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, nullptr, nullptr,
+  MSL_LAUNCH((pw_fwd_bf16_kernel<false, true>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, nullptr, nullptr,
                      w, (u16*)g_in, nullptr, Cin, Cout, S, pb_nofold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -957,17 +957,17 @@ int msl_pwconv_bwd_weight_slabs_bf16(const void* dy, const void* z, const float*
   if (!bww_bf16_plan(N, Cin, Cout, S, mt, tiles, cpi, total, ks, cpb)) {
     dim3 g(msl::cdiv(Cin, 16), msl::cdiv(Cout, 16));
     if (in_scale)
-      hipLaunchKernelGGL(pw_bww_bf16_any_kernel<true>, g, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, in_shift, out,
+      MSL_LAUNCH(pw_bww_bf16_any_kernel<true>, g, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, in_shift, out,
                          N, Cout, Cin, S);
     else
-      hipLaunchKernelGGL(pw_bww_bf16_any_kernel<false>, g, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, in_shift, out,
+      MSL_LAUNCH(pw_bww_bf16_any_kernel<false>, g, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, in_shift, out,
                          N, Cout, Cin, S);
     MSL_LAUNCH_CHECK();
     return MSL_OK;
   }
   dim3 grid(ks, tiles);
 #define MSL_BW(MT_, A_)                                                                                              \
-  hipLaunchKernelGGL((pw_bww_bf16_kernel<MT_, A_>), grid, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, \
+  MSL_LAUNCH((pw_bww_bf16_kernel<MT_, A_>), grid, dim3(256), 0, st, (const u16*)dy, (const u16*)z, in_scale, \
                      in_shift, out, Cout, Cin, S, cpi, total, cpb)
   if (mt == 2) {
     if (in_scale) MSL_BW(2, true); else MSL_BW(2, false);
@@ -991,13 +991,13 @@ int msl_dwconv_bwd_data_bf16(const void* dy, const float* w, void* g_in, int N, 
   if (stride == 1) {  // the forward kernel with reversed taps
     const int tiles_d = msl::cdiv(D, DW_TD), tiles_h = msl::cdiv(H, DW_TH), tiles_w = msl::cdiv(W, DW_TW);
     dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
-    hipLaunchKernelGGL(dw_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)dy, nullptr, nullptr, w, (u16*)g_in, nullptr, C,
+    MSL_LAUNCH(dw_fwd_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)dy, nullptr, nullptr, w, (u16*)g_in, nullptr, C,
                        D, H, W, D, H, W, tiles_h, tiles_w, 0, 1, accumulate);
   } else {
     const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
     const int tiles_d = msl::cdiv(D, DB_TD), tiles_h = msl::cdiv(H, DB_TH), tiles_w = msl::cdiv(W, DB_TW);
     dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
-    hipLaunchKernelGGL(dw_bwd_data_s2_bf16_kernel, grid, dim3(256), 0, st, (const u16*)dy, w, (u16*)g_in, C, D, H, W, OD, OH, OW,
+    MSL_LAUNCH(dw_bwd_data_s2_bf16_kernel, grid, dim3(256), 0, st, (const u16*)dy, w, (u16*)g_in, C, D, H, W, OD, OH, OW,
                        tiles_h, tiles_w, accumulate);
   }
   MSL_LAUNCH_CHECK();
@@ -1016,10 +1016,10 @@ int msl_dwconv_bwd_weight_bf16(const void* dz, const void* x, const float* in_sc
   dim3 grid(tiles_d * tiles_h * tiles_w, N * C);
   hipStream_t st = (hipStream_t)stream;
   if (stride == 1)
-    hipLaunchKernelGGL(dw_bww_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)dz, (const u16*)x, in_scale, in_shift, partials,
+    MSL_LAUNCH(dw_bww_bf16_kernel<1>, grid, dim3(256), 0, st, (const u16*)dz, (const u16*)x, in_scale, in_shift, partials,
                        C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP);
   else
-    hipLaunchKernelGGL(dw_bww_bf16_kernel<2>, grid, dim3(256), 0, st, (const u16*)dz, (const u16*)x, in_scale, in_shift, partials,
+    MSL_LAUNCH(dw_bww_bf16_kernel<2>, grid, dim3(256), 0, st, (const u16*)dz, (const u16*)x, in_scale, in_shift, partials,
                        C, D, H, W, OD, OH, OW, tiles_h, tiles_w, NP);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1032,7 +1032,7 @@ int msl_bn_relu_bwd_reduce_bf16(const void* g, const void* y, const float* scale
                                 const float* invstd, double* partials, int N, int C, int S, void* stream) {
   if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
   const int chunks = msl::cdiv(S, BB_CHUNK);
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_bf16_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, (const u16*)g,
+  MSL_LAUNCH(bn_relu_bwd_reduce_bf16_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, (const u16*)g,
                      (const u16*)y, scale, shift, mean, invstd, partials, C, S, chunks);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1041,7 +1041,7 @@ int msl_bn_relu_bwd_reduce_bf16(const void* g, const void* y, const float* scale
 // vec = (6, C) rows [scale, shift, mean, invstd, c1, c2]; dy may alias g
 int msl_bn_relu_bwd_apply_bf16(const void* g, const void* y, const float* vec, void* dy, int N, int C, int S, void* stream) {
   if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_relu_bwd_apply_bf16_kernel, dim3(std::min(msl::cdiv(S, 1024), 64), C, N), dim3(256), 0, (hipStream_t)stream,
+  MSL_LAUNCH(bn_relu_bwd_apply_bf16_kernel, dim3(std::min(msl::cdiv(S, 1024), 64), C, N), dim3(256), 0, (hipStream_t)stream,
                      (const u16*)g, (const u16*)y, vec, (u16*)dy, C, S);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1054,7 +1054,7 @@ int msl_bn_relu_bwd_fused_bf16(const void* g, const void* y, const float* vec, f
   hipStream_t st = (hipStream_t)stream;
   const long long total8 = (long long)N * (S >> 3);
 #define MSL_BN_REG(NT_, IPT_)                                                                                              \
-  hipLaunchKernelGGL((bn_relu_bwd_fused_reg_bf16_kernel<NT_, IPT_>), dim3(C), dim3(NT_), 0, st, (const u16*)g, (const u16*)y, \
+  MSL_LAUNCH((bn_relu_bwd_fused_reg_bf16_kernel<NT_, IPT_>), dim3(C), dim3(NT_), 0, st, (const u16*)g, (const u16*)y, \
                      vec, dgamma, dbeta, (u16*)dy, N, C, S, (double)N * (double)S)
   if ((S & 7) == 0 && total8 <= 4096) {
     if (total8 <= 64) MSL_BN_REG(64, 1);
@@ -1067,7 +1067,7 @@ int msl_bn_relu_bwd_fused_bf16(const void* g, const void* y, const float* vec, f
     return MSL_OK;
   }
 #undef MSL_BN_REG
-  hipLaunchKernelGGL(bn_relu_bwd_fused_bf16_kernel, dim3(C), dim3(256), 0, st, (const u16*)g, (const u16*)y, vec,
+  MSL_LAUNCH(bn_relu_bwd_fused_bf16_kernel, dim3(C), dim3(256), 0, st, (const u16*)g, (const u16*)y, vec,
                      dgamma, dbeta, (u16*)dy, N, C, S, (double)N * (double)S);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

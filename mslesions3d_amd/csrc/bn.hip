@@ -459,7 +459,7 @@ int msl_bn_finalize(const double* partials, int num_partials, double count, cons
                     float* save_mean, float* save_invstd, int C, void* stream) {
   if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
   const msl::BnFold f{partials, num_partials, C, count, gamma, beta, eps};
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, f, running_mean, running_var,
+  MSL_LAUNCH(bn_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, f, running_mean, running_var,
                      num_batches_tracked, momentum, scale, shift, save_mean, save_invstd);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -490,7 +490,7 @@ int msl_bn_finalize_table_set(void* host_table, int index, int first_block, cons
 
 int msl_bn_finalize_batch(const void* device_table, int n_entries, int total_channels, void* stream) {
   if (!device_table || n_entries <= 0 || total_channels <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_finalize_batch_kernel, dim3(total_channels), dim3(64), 0, (hipStream_t)stream,
+  MSL_LAUNCH(bn_finalize_batch_kernel, dim3(total_channels), dim3(64), 0, (hipStream_t)stream,
                      reinterpret_cast<const BnFinalizeEntry*>(device_table), n_entries);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -499,7 +499,7 @@ int msl_bn_finalize_batch(const void* device_table, int n_entries, int total_cha
 // eval-mode (scale, shift) of every BatchNorm listed in the table (msl_bn_finalize_table_set) in ONE launch
 int msl_bn_eval_affine_batch(const void* device_table, int n_entries, int total_channels, void* stream) {
   if (!device_table || n_entries <= 0 || total_channels <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_eval_affine_batch_kernel, dim3(msl::cdiv(total_channels, 128)), dim3(128), 0, (hipStream_t)stream,
+  MSL_LAUNCH(bn_eval_affine_batch_kernel, dim3(msl::cdiv(total_channels, 128)), dim3(128), 0, (hipStream_t)stream,
                      reinterpret_cast<const BnFinalizeEntry*>(device_table), n_entries, total_channels);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -508,7 +508,7 @@ int msl_bn_eval_affine_batch(const void* device_table, int n_entries, int total_
 int msl_bn_eval_affine(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, int C, void* stream) {
   if (C <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3(msl::cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma,
+  MSL_LAUNCH(bn_eval_affine_kernel, dim3(msl::cdiv(C, 128)), dim3(128), 0, (hipStream_t)stream, gamma,
                      beta, running_mean, running_var, eps, scale, shift, C);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -520,7 +520,7 @@ int msl_bn_relu_materialize(const float* y, const float* scale, const float* shi
   const int S = D * H * W;
   dim3 grid(min(msl::cdiv((W & 3) == 0 ? S / 4 : S, 256), 64), N * C);
   const msl::BnFold nofold{nullptr, 0, C, 1.0, nullptr, nullptr, 0.f};
-  hipLaunchKernelGGL(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, nofold,
+  MSL_LAUNCH(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, scale, shift, nofold,
                      out_plain, out_pad, C, D, H, W);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -534,7 +534,7 @@ int msl_bn_relu_materialize_fold(const float* y, const double* partials, int num
   const int S = D * H * W;
   dim3 grid(min(msl::cdiv((W & 3) == 0 ? S / 4 : S, 256), 64), N * C);
   const msl::BnFold f{partials, num_partials, C, count, gamma, beta, eps};
-  hipLaunchKernelGGL(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, nullptr, nullptr, f,
+  MSL_LAUNCH(bn_relu_materialize_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, nullptr, nullptr, f,
                      out_plain, out_pad, C, D, H, W);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -547,7 +547,7 @@ int msl_bn_relu_bwd_reduce(const float* g, const float* y, const float* scale, c
                            void* stream) {
   if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
   const int chunks = msl::cdiv(S, BWD_CHUNK);
-  hipLaunchKernelGGL(bn_relu_bwd_reduce_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, g, y,
+  MSL_LAUNCH(bn_relu_bwd_reduce_kernel, dim3(chunks, C, N), dim3(256), 0, (hipStream_t)stream, g, y,
                      scale, shift, mean, invstd, partials, C, S, chunks);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -556,7 +556,7 @@ int msl_bn_relu_bwd_reduce(const float* g, const float* y, const float* scale, c
 int msl_bn_bwd_finalize(const double* partials, int num_partials, double count, float* dgamma, float* dbeta,
                         float* c1, float* c2, int C, void* stream) {
   if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
+  MSL_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
                      count, dgamma, dbeta, c1, c2, C, (const float*)nullptr, (float*)nullptr);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -567,7 +567,7 @@ int msl_bn_bwd_finalize(const double* partials, int num_partials, double count, 
 int msl_bn_bwd_finalize_coef(const double* partials, int num_partials, double count, float* dgamma, float* dbeta,
                              float* bn_vec, int C, void* stream) {
   if (C <= 0 || num_partials <= 0 || !bn_vec) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
+  MSL_LAUNCH(bn_bwd_finalize_kernel, dim3(C), dim3(64), 0, (hipStream_t)stream, partials, num_partials,
                      count, dgamma, dbeta, bn_vec + 4 * C, bn_vec + 5 * C, C, (const float*)bn_vec, bn_vec + 6 * C);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -581,7 +581,7 @@ int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, co
   hipStream_t st = (hipStream_t)stream;
   const long long total4 = (long long)N * (S >> 2);
 #define MSL_BN_REG(NT_, IPT_)                                                                                          \
-  hipLaunchKernelGGL((bn_relu_bwd_fused_reg_kernel<NT_, IPT_>), dim3(C), dim3(NT_), 0, st, g, y, scale, shift, mean, \
+  MSL_LAUNCH((bn_relu_bwd_fused_reg_kernel<NT_, IPT_>), dim3(C), dim3(NT_), 0, st, g, y, scale, shift, mean, \
                      invstd, dgamma, dbeta, dy, N, C, S, (double)N * S)
   if ((S & 3) == 0 && total4 <= 4096) {
     if (total4 <= 64) MSL_BN_REG(64, 1);
@@ -594,7 +594,7 @@ int msl_bn_relu_bwd_fused(const float* g, const float* y, const float* scale, co
     return MSL_OK;
   }
 #undef MSL_BN_REG
-  hipLaunchKernelGGL(bn_relu_bwd_fused_kernel, dim3(C), dim3(256), 0, st, g, y, scale, shift, mean,
+  MSL_LAUNCH(bn_relu_bwd_fused_kernel, dim3(C), dim3(256), 0, st, g, y, scale, shift, mean,
                      invstd, dgamma, dbeta, dy, N, C, S, (double)N * S);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -605,7 +605,7 @@ int msl_bn_relu_bwd_apply(const float* g, const float* y, const float* scale, co
                           int N, int C, int S, void* stream) {
   if (N <= 0 || C <= 0 || S <= 0) return MSL_ERR_ARG;
   const int gx = min(msl::cdiv(S, 1024), 64);
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, g, y, scale,
+  MSL_LAUNCH(bn_relu_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, g, y, scale,
                      shift, mean, invstd, c1, c2, dy, C, S, (const double*)nullptr, 0, 1.0, (float*)nullptr,
                      (float*)nullptr, (float*)nullptr, (float*)nullptr);
   MSL_LAUNCH_CHECK();
@@ -619,7 +619,7 @@ int msl_bn_relu_bwd_finalize_apply(const double* partials, int num_partials, dou
                                    void* stream) {
   if (N <= 0 || C <= 0 || S <= 0 || num_partials <= 0 || !partials || !bn_vec) return MSL_ERR_ARG;
   const int gx = min(msl::cdiv(S, 1024), 64);
-  hipLaunchKernelGGL(bn_relu_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, g, y, bn_vec,
+  MSL_LAUNCH(bn_relu_bwd_apply_kernel, dim3(gx, C, N), dim3(256), 0, (hipStream_t)stream, g, y, bn_vec,
                      bn_vec + C, bn_vec + 2 * C, bn_vec + 3 * C, (const float*)nullptr, (const float*)nullptr, dy, C, S,
                      partials, num_partials, count, dgamma, dbeta, bn_vec + 4 * C, bn_vec + 5 * C);
   MSL_LAUNCH_CHECK();

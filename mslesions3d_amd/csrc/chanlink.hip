@@ -332,7 +332,7 @@ static int link_launch(T* g_z, const T* z, const float* vec_z, const float* w_dw
   do {                                                                                                                   \
     auto k = block_bwd_channel_link_kernel<T, NW_, QO_, QI_, S_, B_>;                                                    \
     if (p.smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.smem); \
-    hipLaunchKernelGGL(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
+    MSL_LAUNCH(k, dim3(C), dim3(NW_ * 64), p.smem, st, g_z, z, vec_z, w_dw, y_prev, vec_y, g_y, dgamma_z, dbeta_z, \
                        dgamma_y, dbeta_y, dw_dw, N, C, p.lD, p.lH, p.lW, accumulate);                                     \
   } while (0)
 #define MSL_LINK_S(NW_, QO_, QI_, S_)                  \

@@ -16,6 +16,58 @@
     if (e__ != hipSuccess) return (int)e__;     \
   } while (0)
 
+// ---- kernel launches -------------------------------------------------------------------------------------------
+// Every launch of the library goes through MSL_LAUNCH.  Normally that IS hipLaunchKernelGGL.  If the calling thread has
+// armed a stop event (msl_arm_stop_event, optim.hip), the launch that the arming names carries the event as the stopEvent
+// of hipExtLaunchKernel: the event completes with that kernel's own completion signal and the stream gets NO separate
+// record (barrier) packet.  Measured on MI355X (tools/probes/evrec.hip, chain of dependent kernels, a second stream waiting
+// for each): fork by hipEventRecord +4.9 us per kernel on the recording stream, by a hipEventDisableSystemFence event
+// +2.4 us, by stop event +1.2 us.
+#include <hip/hip_ext.h>
+#include <tuple>
+#include <utility>
+namespace msl {
+struct StopEventArm {
+  hipEvent_t ev = nullptr;  // armed event (nullptr: none)
+  int skip = 0;             // launches to let pass before the one that takes the event
+  unsigned launches = 0;    // launches issued by this thread so far (the recorder learns launches-per-entry-point from it)
+};
+StopEventArm& stop_event_arm();  // thread-local, defined in optim.hip
+
+inline hipEvent_t take_stop_event() {
+  StopEventArm& a = stop_event_arm();
+  ++a.launches;
+  if (a.ev == nullptr) return nullptr;
+  if (a.skip > 0) {
+    --a.skip;
+    return nullptr;
+  }
+  hipEvent_t e = a.ev;
+  a.ev = nullptr;
+  return e;
+}
+
+template <typename... KArgs, size_t... I>
+inline void launch_with_stop_event(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned smem, hipStream_t st,
+                                   hipEvent_t stop, std::tuple<KArgs...>& vals, std::index_sequence<I...>) {
+  void* ptrs[sizeof...(KArgs) > 0 ? sizeof...(KArgs) : 1] = {(void*)&std::get<I>(vals)...};
+  (void)hipExtLaunchKernel(reinterpret_cast<const void*>(kernel), grid, block, ptrs, smem, st, nullptr, stop, 0);
+}
+
+template <typename... KArgs, typename... Args>
+inline void launch(void (*kernel)(KArgs...), dim3 grid, dim3 block, unsigned smem, hipStream_t st, Args&&... args) {
+  static_assert(sizeof...(KArgs) == sizeof...(Args), "kernel argument count");
+  hipEvent_t stop = take_stop_event();
+  if (stop == nullptr) {
+    hipLaunchKernelGGL(kernel, grid, block, smem, st, std::forward<Args>(args)...);
+  } else {
+    std::tuple<KArgs...> vals{static_cast<KArgs>(args)...};  // the kernel's own parameter types, addressable
+    launch_with_stop_event(kernel, grid, block, smem, st, stop, vals, std::index_sequence_for<KArgs...>{});
+  }
+}
+}  // namespace msl
+#define MSL_LAUNCH(kernel, ...) msl::launch(kernel, __VA_ARGS__)
+
 namespace msl {
 
 // ---- cross-lane sums on the VALU (DPP) -------------------------------------------------------------------------

@@ -397,23 +397,23 @@ int msl_detect_objects(const float* locs, const float* scores, const float* prio
   const int Wn = msl::cdiv(cap, 64), ncls1 = ncls - 1;
   hipStream_t st = (hipStream_t)stream;
   if (msl_detect_select_ws_ints(N, P, ncls) >= (1ull << 31) || N * ncls1 > N * P) return MSL_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(detect_prepare_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores, priors_c, probs, boxes,
+  MSL_LAUNCH(detect_prepare_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores, priors_c, probs, boxes,
                      N, P, ncls, select_ws, (int)msl_detect_select_ws_ints(N, P, ncls), ncand, N * ncls1);
   MSL_LAUNCH_CHECK();
   const dim3 gp(msl::cdiv(P, 256), N * ncls1);
-  hipLaunchKernelGGL(detect_hist_kernel, gp, dim3(256), 0, st, probs, min_score, P, select_ws, ncand);
+  MSL_LAUNCH(detect_hist_kernel, gp, dim3(256), 0, st, probs, min_score, P, select_ws, ncand);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(detect_threshold_kernel, dim3(N * ncls1), dim3(64), 0, st, select_ws, P, cap);
+  MSL_LAUNCH(detect_threshold_kernel, dim3(N * ncls1), dim3(64), 0, st, select_ws, P, cap);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(detect_compact_kernel, gp, dim3(256), 0, st, probs, min_score, P, select_ws);
+  MSL_LAUNCH(detect_compact_kernel, gp, dim3(256), 0, st, probs, min_score, P, select_ws);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(detect_rank_kernel, gp, dim3(256), 0, st, probs, P, cap, select_ws, sorted_idx);
+  MSL_LAUNCH(detect_rank_kernel, gp, dim3(256), 0, st, probs, P, cap, select_ws, sorted_idx);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(detect_mask_kernel, dim3(msl::cdiv(cap, 4), N * ncls1), dim3(256), 0, st, boxes, sorted_idx, ncand, max_overlap, P, cap, Wn, ncls1, mask);
+  MSL_LAUNCH(detect_mask_kernel, dim3(msl::cdiv(cap, 4), N * ncls1), dim3(256), 0, st, boxes, sorted_idx, ncand, max_overlap, P, cap, Wn, ncls1, mask);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(detect_scan_kernel, dim3(N * ncls1), dim3(256), 0, st, mask, ncand, cap, Wn, keep_bits, nkept);
+  MSL_LAUNCH(detect_scan_kernel, dim3(N * ncls1), dim3(256), 0, st, mask, ncand, cap, Wn, keep_bits, nkept);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(detect_finalize_kernel, dim3(N), dim3(256), 0, st, probs, boxes, sorted_idx, keep_bits, nkept, P, cap, Wn, ncls1, top_k, out_boxes, out_scores, out_labels, out_prior, out_count, tmp_scores, tmp_ref);
+  MSL_LAUNCH(detect_finalize_kernel, dim3(N), dim3(256), 0, st, probs, boxes, sorted_idx, keep_bits, nkept, P, cap, Wn, ncls1, top_k, out_boxes, out_scores, out_labels, out_prior, out_count, tmp_scores, tmp_ref);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -1520,13 +1520,13 @@ void launch_wave(const WavePlan& wp, const T* x, const float* in_scale, const fl
   const dim3 grid(msl::cdiv(waves, 4)), block(256);
 #define MSL_DW_WAVE_SL(LW_, LH_)                                                                                  \
   switch (wp.SL) {                                                                                                \
-    case 8: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 8, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    case 8: MSL_LAUNCH((dw_s1_wave_kernel<LW_, LH_, 8, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
-    case 4: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    case 4: MSL_LAUNCH((dw_s1_wave_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
-    case 2: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    case 2: MSL_LAUNCH((dw_s1_wave_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                      \
-    default: hipLaunchKernelGGL((dw_s1_wave_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    default: MSL_LAUNCH((dw_s1_wave_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                 partials, C, D, wp.nslabs, N, flip, accumulate, fold); break;                     \
   }
   if (wp.logw4 == 0) { MSL_DW_WAVE_SL(0, 2) }
@@ -1543,11 +1543,11 @@ void launch_wave_s2(const WavePlan& wp, const T* x, const float* in_scale, const
   const dim3 grid(msl::cdiv(waves, wpg)), block(64 * wpg);
 #define MSL_DW_WAVE2_SL(LW_, LH_)                                                                                  \
   switch (wp.SL) {                                                                                                 \
-    case 4: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
+    case 4: MSL_LAUNCH((dw_s2_wave_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
                                partials, C, D, OD, wp.nslabs, N, fold); break;                                     \
-    case 2: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
+    case 2: MSL_LAUNCH((dw_s2_wave_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y,  \
                                partials, C, D, OD, wp.nslabs, N, fold); break;                                     \
-    default: hipLaunchKernelGGL((dw_s2_wave_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
+    default: MSL_LAUNCH((dw_s2_wave_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, \
                                 partials, C, D, OD, wp.nslabs, N, fold); break;                                    \
   }
   if (wp.logw4 == 1) { MSL_DW_WAVE2_SL(1, 2) }
@@ -1577,11 +1577,11 @@ void launch_rows_eval(const T* x, const float* in_scale, const float* in_shift, 
     const int waves = N * C * nslabs * RG;
     const dim3 grid(msl::cdiv(waves, 4)), block(256);
     switch (SL) {
-      case 4: hipLaunchKernelGGL((dw_s1_rows_eval_kernel<4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
+      case 4: MSL_LAUNCH((dw_s1_rows_eval_kernel<4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
                                  nslabs, RPW, RG, waves); break;
-      case 2: hipLaunchKernelGGL((dw_s1_rows_eval_kernel<2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
+      case 2: MSL_LAUNCH((dw_s1_rows_eval_kernel<2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
                                  nslabs, RPW, RG, waves); break;
-      default: hipLaunchKernelGGL((dw_s1_rows_eval_kernel<1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
+      default: MSL_LAUNCH((dw_s1_rows_eval_kernel<1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W,
                                   nslabs, RPW, RG, waves); break;
     }
     return;
@@ -1591,11 +1591,11 @@ void launch_rows_eval(const T* x, const float* in_scale, const float* in_shift, 
   const int waves = N * C * nslabs * RG;
   const dim3 grid(msl::cdiv(waves, 4)), block(256);
   switch (SL) {
-    case 4: hipLaunchKernelGGL((dw_s2_rows_eval_kernel<4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
+    case 4: MSL_LAUNCH((dw_s2_rows_eval_kernel<4, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
                                nslabs, RPW, RG, waves); break;
-    case 2: hipLaunchKernelGGL((dw_s2_rows_eval_kernel<2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
+    case 2: MSL_LAUNCH((dw_s2_rows_eval_kernel<2, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
                                nslabs, RPW, RG, waves); break;
-    default: hipLaunchKernelGGL((dw_s2_rows_eval_kernel<1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
+    default: MSL_LAUNCH((dw_s2_rows_eval_kernel<1, T>), grid, block, 0, st, x, in_scale, in_shift, w, y, C, D, H, W, OD,
                                 nslabs, RPW, RG, waves); break;
   }
 }
@@ -1616,13 +1616,13 @@ void launch_wave_bww(const WavePlan& wp, int stride, const T* x, const float* in
     const dim3 grid(msl::cdiv(waves, 4)), block(256);
 #define MSL_DW_WAVE_BWW1(LW_, LH_)                                                                                \
   switch (wp.SL) {                                                                                                \
-    case 8: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 8, T>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 8: MSL_LAUNCH((dw_s1_wave_bww_kernel<LW_, LH_, 8, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, wp.nslabs, N); break;                                          \
-    case 4: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 4: MSL_LAUNCH((dw_s1_wave_bww_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, wp.nslabs, N); break;                                          \
-    case 2: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 2: MSL_LAUNCH((dw_s1_wave_bww_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, wp.nslabs, N); break;                                          \
-    default: hipLaunchKernelGGL((dw_s1_wave_bww_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift,  \
+    default: MSL_LAUNCH((dw_s1_wave_bww_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift,  \
                                 dy, partials, C, D, wp.nslabs, N); break;                                         \
   }
     if (wp.logw4 == 0) { MSL_DW_WAVE_BWW1(0, 2) }
@@ -1635,11 +1635,11 @@ void launch_wave_bww(const WavePlan& wp, int stride, const T* x, const float* in
   const dim3 grid(msl::cdiv(waves, wpg)), block(64 * wpg);
 #define MSL_DW_WAVE_BWW2(LW_, LH_)                                                                                \
   switch (wp.SL) {                                                                                                \
-    case 4: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 4: MSL_LAUNCH((dw_s2_wave_bww_kernel<LW_, LH_, 4, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, OD, wp.nslabs, N); break;                                      \
-    case 2: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift,   \
+    case 2: MSL_LAUNCH((dw_s2_wave_bww_kernel<LW_, LH_, 2, T>), grid, block, 0, st, x, in_scale, in_shift,   \
                                dy, partials, C, D, OD, wp.nslabs, N); break;                                      \
-    default: hipLaunchKernelGGL((dw_s2_wave_bww_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift,  \
+    default: MSL_LAUNCH((dw_s2_wave_bww_kernel<LW_, LH_, 1, T>), grid, block, 0, st, x, in_scale, in_shift,  \
                                 dy, partials, C, D, OD, wp.nslabs, N); break;                                     \
   }
   if (wp.logw4 == 1) { MSL_DW_WAVE_BWW2(1, 2) }
@@ -1774,7 +1774,7 @@ int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in
   do {                                                                                                          \
     int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_, 1>, lds);                                                 \
     if (e_) return e_;                                                                                          \
-    hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale,   \
+    MSL_LAUNCH((dw_fwd_stream_kernel<S_, I_, L_, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale,   \
                        in_shift, nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N, nofold); \
   } while (0)
     if (stride == 2) {
@@ -1789,12 +1789,12 @@ int msl_dwconv_bwd_weight_tiled(const float* dy, const float* x, const float* in
     if (stride == 2) {
       int e_ = set_lds(dw_fwd_resident_kernel<2, 1>, lds);
       if (e_) return e_;
-      hipLaunchKernelGGL((dw_fwd_resident_kernel<2, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
+      MSL_LAUNCH((dw_fwd_resident_kernel<2, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
                          nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, nofold);
     } else {
       int e_ = set_lds(dw_fwd_resident_kernel<1, 1>, lds);
       if (e_) return e_;
-      hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
+      MSL_LAUNCH((dw_fwd_resident_kernel<1, 1>), dim3(nblocks), dim3(256), lds, st, x, in_scale, in_shift,
                          nullptr, dyp, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, nofold);
     }
   }
@@ -1826,7 +1826,7 @@ int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in
   const int nblocks = N * (C / pl.G) * pl.nslabs;
   int e_ = set_lds(dw_fwd_resident_kernel<1, 0>, pl.lds_bytes);
   if (e_) return e_;
-  hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, (hipStream_t)stream, dy,
+  MSL_LAUNCH((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, (hipStream_t)stream, dy,
                      nullptr, nullptr, w, g_in, nullptr, C, D, H, W, D, H, W, pl.G, pl.SLAB, pl.nslabs, N, 1, accumulate, nofold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1859,12 +1859,12 @@ static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* i
   }
   if (pl.variant == 0) {
     const int S = OD * OH * OW;
-    hipLaunchKernelGGL(dw_fwd_naive_kernel, dim3(std::min(msl::cdiv(S, 256), 256), N * C), dim3(256), 0, st, x,
+    MSL_LAUNCH(dw_fwd_naive_kernel, dim3(std::min(msl::cdiv(S, 256), 256), N * C), dim3(256), 0, st, x,
                        in_scale, in_shift, w, y, C, D, H, W, OD, OH, OW, stride, fold);
     MSL_LAUNCH_CHECK();
     if (partials) {
       const int chunks = msl::cdiv(S, STATS_CHUNK);
-      hipLaunchKernelGGL(channel_stats_kernel, dim3(chunks, C, N), dim3(256), 0, st, y, partials, C, S, chunks);
+      MSL_LAUNCH(channel_stats_kernel, dim3(chunks, C, N), dim3(256), 0, st, y, partials, C, S, chunks);
       MSL_LAUNCH_CHECK();
     }
     return MSL_OK;
@@ -1875,7 +1875,7 @@ static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* i
   do {                                                                                                         \
     int e_ = set_lds(dw_fwd_stream_kernel<S_, I_, L_, 0>, pl.lds_bytes);                                          \
     if (e_) return e_;                                                                                         \
-    hipLaunchKernelGGL((dw_fwd_stream_kernel<S_, I_, L_, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x,      \
+    MSL_LAUNCH((dw_fwd_stream_kernel<S_, I_, L_, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x,      \
                        in_scale, in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.SLAB, pl.nslabs, N, fold);  \
   } while (0)
     if (stride == 2) {
@@ -1890,12 +1890,12 @@ static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* i
     if (stride == 2) {
       int e_ = set_lds(dw_fwd_resident_kernel<2, 0>, pl.lds_bytes);
       if (e_) return e_;
-      hipLaunchKernelGGL((dw_fwd_resident_kernel<2, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
+      MSL_LAUNCH((dw_fwd_resident_kernel<2, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
                          in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, fold);
     } else {
       int e_ = set_lds(dw_fwd_resident_kernel<1, 0>, pl.lds_bytes);
       if (e_) return e_;
-      hipLaunchKernelGGL((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
+      MSL_LAUNCH((dw_fwd_resident_kernel<1, 0>), dim3(nblocks), dim3(256), pl.lds_bytes, st, x, in_scale,
                          in_shift, w, y, partials, C, D, H, W, OD, OH, OW, pl.G, pl.SLAB, pl.nslabs, N, 0, 0, fold);
     }
   }

@@ -507,15 +507,15 @@ int msl_dwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
   if (W % 4 == 0) {
     if (stride == 2) {
       dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
-      hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<false, float>), grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW,
+      MSL_LAUNCH((dw_bwd_data_s2_patch_kernel<false, float>), grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW,
                          accumulate, (const float*)nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     } else {
       dim3 grid(msl::cdiv(D * H * (W / 4), 256), N * C);
-      hipLaunchKernelGGL(dw_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
+      MSL_LAUNCH(dw_bwd_data_kernel<1>, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, accumulate);
     }
   } else {
     dim3 grid(std::min(msl::cdiv(D * H * W, 256), 256), N * C);
-    hipLaunchKernelGGL(dw_bwd_data_naive_kernel, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, stride, accumulate);
+    MSL_LAUNCH(dw_bwd_data_naive_kernel, grid, dim3(256), 0, st, dy, w, g_in, C, D, H, W, OD, OH, OW, stride, accumulate);
   }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -537,7 +537,7 @@ int msl_dwconv_bwd_data_bnreduce(const float* dy, const float* w, float* g_in, c
   if (stride != 2 || W % 4 != 0) return MSL_ERR_UNSUPPORTED;
   const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256), N * C);
-  hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<true, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, g_in, C, D, H, W,
+  MSL_LAUNCH((dw_bwd_data_s2_patch_kernel<true, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, g_in, C, D, H, W,
                      OD, OH, OW, accumulate, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, partials);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -555,11 +555,11 @@ int msl_dwconv_bwd_data_s2_patch_bf16(const void* dy, const float* w, void* g_in
   typedef msl::su16 u16;
   if (y_prev) {
     if (!bn_vec || !partials) return MSL_ERR_ARG;
-    hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<true, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w,
+    MSL_LAUNCH((dw_bwd_data_s2_patch_kernel<true, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w,
                        (u16*)g_in, C, D, H, W, OD, OH, OW, accumulate, (const u16*)y_prev, bn_vec, bn_vec + C, bn_vec + 2 * C,
                        bn_vec + 3 * C, partials);
   } else {
-    hipLaunchKernelGGL((dw_bwd_data_s2_patch_kernel<false, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w,
+    MSL_LAUNCH((dw_bwd_data_s2_patch_kernel<false, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w,
                        (u16*)g_in, C, D, H, W, OD, OH, OW, accumulate, (const u16*)nullptr, nullptr, nullptr, nullptr, nullptr,
                        nullptr);
   }
@@ -586,7 +586,7 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
     if (rc == MSL_OK) {
       if (!dw) return MSL_OK;
       const int NPt = msl_dwconv_bwd_weight_tiled_num_partials(N, C, D, H, W, stride);
-      hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, NPt, dw, C * 27);
+      MSL_LAUNCH(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, NPt, dw, C * 27);
       MSL_LAUNCH_CHECK();
       return MSL_OK;
     }
@@ -594,11 +594,11 @@ int msl_dwconv_bwd_weight(const float* dy, const float* x, const float* in_scale
   }
   const int chunks = msl::cdiv(OD * OH * OW, BW_CHUNK);
   const int total_items = N * C * chunks;
-  hipLaunchKernelGGL(dw_bwd_weight_kernel, dim3(msl::cdiv(total_items, 4)), dim3(256), 0, st, dy, x, in_scale, in_shift,
+  MSL_LAUNCH(dw_bwd_weight_kernel, dim3(msl::cdiv(total_items, 4)), dim3(256), 0, st, dy, x, in_scale, in_shift,
                      partials, C, D, H, W, OD, OH, OW, stride, chunks, N * chunks, total_items);
   MSL_LAUNCH_CHECK();
   if (!dw) return MSL_OK;
-  hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, N * chunks, dw, C * 27);
+  MSL_LAUNCH(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, st, partials, N * chunks, dw, C * 27);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -624,7 +624,7 @@ int msl_dwconv_s2_bwd_bnreduce_bww(const float* dy, const float* w, const float*
   if (W % 4 != 0) return MSL_ERR_UNSUPPORTED;
   const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
-  hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
+  MSL_LAUNCH((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
                      OH, OW, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, bn_partials, w_partials, w_taps_t, (float*)nullptr, 0);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -642,7 +642,7 @@ int msl_dwconv_s2_bwd_data_bnreduce_bww(const float* dy, const float* w, float* 
   if (W % 4 != 0) return MSL_ERR_UNSUPPORTED;
   const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
-  hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
+  MSL_LAUNCH((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, float>), grid, dim3(256), 0, (hipStream_t)stream, dy, w, C, D, H, W, OD,
                      OH, OW, y_prev, bn_scale, bn_shift, bn_mean, bn_invstd, bn_partials, w_partials, (float*)nullptr, g_in,
                      accumulate);
   MSL_LAUNCH_CHECK();
@@ -658,7 +658,7 @@ int msl_dwconv_s2_bwd_bnreduce_bww_bf16(const void* dy, const float* w, const vo
   const int OD = (D - 1) / 2 + 1, OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1;
   dim3 grid(msl::cdiv(((D + 1) / 2) * ((H + 1) / 2) * (W / 4), 256 * S2F_PPT), N * C);
   typedef msl::su16 u16;
-  hipLaunchKernelGGL((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w, C,
+  MSL_LAUNCH((dw_s2_bwd_reduce_bww_kernel<S2F_PPT, u16>), grid, dim3(256), 0, (hipStream_t)stream, (const u16*)dy, w, C,
                      D, H, W, OD, OH, OW, (const u16*)y_prev, bn_vec, bn_vec + C, bn_vec + 2 * C, bn_vec + 3 * C, bn_partials,
                      w_partials, w_taps_t, (u16*)nullptr, 0);
   MSL_LAUNCH_CHECK();
@@ -668,7 +668,7 @@ int msl_dwconv_s2_bwd_bnreduce_bww_bf16(const void* dy, const float* w, const vo
 // dw[c][k] = sum_p w_partials[c*27+k][p]  (fixed order)
 int msl_dwconv_bwd_weight_finalize(const double* w_partials, int num_partials, float* dw, int C, void* stream) {
   if (C <= 0 || num_partials <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, (hipStream_t)stream, w_partials,
+  MSL_LAUNCH(dw_bwd_weight_finalize_kernel, dim3(C * 27), dim3(64), 0, (hipStream_t)stream, w_partials,
                      num_partials, dw, C * 27);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

@@ -1034,7 +1034,7 @@ int msl_head_pack_weights(const float* loc_w, const float* cl_w, float* Wf, floa
   if (C % 16 != 0 || ncls < 1 || head_mt(ncls) > 2) return MSL_ERR_ARG;
   const int MT = head_mt(ncls);
   const int total = C / 4 * 27 * MT * 64;
-  hipLaunchKernelGGL(head_pack_weights_kernel, dim3(std::min(msl::cdiv(total, 256), 1024)), dim3(256), 0,
+  MSL_LAUNCH(head_pack_weights_kernel, dim3(std::min(msl::cdiv(total, 256), 1024)), dim3(256), 0,
                      (hipStream_t)stream, loc_w, cl_w, Wf, Wb, C, 12 + 2 * ncls, MT);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1053,7 +1053,7 @@ int msl_head_pack_weights_batch(const float* const* loc_w, const float* const* c
   }
   const int MT = head_mt(ncls);
   const int total = cmax / 4 * 27 * MT * 64;
-  hipLaunchKernelGGL(head_pack_weights_batch_kernel, dim3(std::min(msl::cdiv(total, 256), 512), n), dim3(256), 0,
+  MSL_LAUNCH(head_pack_weights_batch_kernel, dim3(std::min(msl::cdiv(total, 256), 512), n), dim3(256), 0,
                      (hipStream_t)stream, b, 12 + 2 * ncls, MT);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1065,7 +1065,7 @@ size_t msl_head_packed_weight_bf16_elems(int C) { return (size_t)27 * (C / 32) *
 int msl_head_pack_weights_bf16(const float* loc_w, const float* cl_w, void* Wp, int C, int ncls, void* stream) {
   if (C % 32 != 0 || ncls < 1 || 12 + 2 * ncls > 16) return MSL_ERR_UNSUPPORTED;
   const int total = 27 * (C / 32) * 64;
-  hipLaunchKernelGGL(head_pack_weights_bf16_kernel, dim3(std::min(msl::cdiv(total, 256), 512)), dim3(256), 0,
+  MSL_LAUNCH(head_pack_weights_bf16_kernel, dim3(std::min(msl::cdiv(total, 256), 512)), dim3(256), 0,
                      (hipStream_t)stream, loc_w, cl_w, (hu16*)Wp, C, 12 + 2 * ncls);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1078,7 +1078,7 @@ int msl_head_conv_fwd_bf16(const void* a_cl, const void* Wp, const float* loc_b,
   if (N <= 0 || D <= 0 || H <= 0 || W <= 0 || ncls < 1) return MSL_ERR_ARG;
   if (C % 32 != 0 || 12 + 2 * ncls > 16) return MSL_ERR_UNSUPPORTED;
   const int S = D * H * W;
-  hipLaunchKernelGGL(head_fwd_bf16_kernel, dim3(msl::cdiv(S, 64), N), dim3(256), 0, (hipStream_t)stream, (const hu16*)a_cl,
+  MSL_LAUNCH(head_fwd_bf16_kernel, dim3(msl::cdiv(S, 64), N), dim3(256), 0, (hipStream_t)stream, (const hu16*)a_cl,
                      (const hu16*)Wp, loc_b, cl_b, locs, scores, C, D, H, W, Ptot, prior_off, ncls, 12 + 2 * ncls);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1103,7 +1103,7 @@ int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, c
 #define MSL_HF(W_, MT_)                                                                                              \
   do {                                                                                                               \
     const size_t smem = ((size_t)HEAD_FWD_CH * HeadGeo<W_>::CS + (size_t)(HEAD_FWD_CH / 4) * 27 * MT_ * 64) * sizeof(float); \
-    hipLaunchKernelGGL((head_fwd_lds_kernel<W_, MT_>), grid, dim3(HEAD_FWD_NT), smem, st, a_pad, Wf, loc_b, cl_b, locs,  \
+    MSL_LAUNCH((head_fwd_lds_kernel<W_, MT_>), grid, dim3(HEAD_FWD_NT), smem, st, a_pad, Wf, loc_b, cl_b, locs,  \
                        scores, workspace, C, D, Ptot, prior_off, ncls, co_total, ksg);                                \
   } while (0)
     // (chunks of 32 channels - half the barriers, twice the MFMA time per prefetch - measured equal: 27.3 vs 28.0 us at 16^3)
@@ -1112,14 +1112,14 @@ int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, c
   } else {
     dim3 grid(msl::cdiv(S, 32), N, ksg);
     if (MT == 1)
-      hipLaunchKernelGGL(head_fwd_kernel<1>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
+      MSL_LAUNCH(head_fwd_kernel<1>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
     else
-      hipLaunchKernelGGL(head_fwd_kernel<2>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
+      MSL_LAUNCH(head_fwd_kernel<2>, grid, dim3(256), 0, st, a_pad, Wf, loc_b, cl_b, locs, scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);
   }
   MSL_LAUNCH_CHECK();
   if (ksg > 1) {
     const int total = N * S * 4 * MT;
-    hipLaunchKernelGGL(head_fwd_finalize_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, st, workspace, loc_b,
+    MSL_LAUNCH(head_fwd_finalize_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, st, workspace, loc_b,
                        cl_b, locs, scores, N, S, MT, ksg, Ptot, prior_off, ncls, co_total);
     MSL_LAUNCH_CHECK();
   }
@@ -1131,7 +1131,7 @@ int msl_head_grad_pack(const float* dlocs, const float* dscores, float* dO_pad, 
                        int Ptot, int prior_off, int ncls, void* stream) {
   const int MT = head_mt(ncls), CO = 16 * MT;
   const int total = N * CO * D * H * W;
-  hipLaunchKernelGGL(head_grad_pack_kernel, dim3(std::min(msl::cdiv(total, 256), 2048)), dim3(256), 0,
+  MSL_LAUNCH(head_grad_pack_kernel, dim3(std::min(msl::cdiv(total, 256), 2048)), dim3(256), 0,
                      (hipStream_t)stream, dlocs, dscores, dO_pad, N, D, H, W, CO, Ptot, prior_off, ncls,
                      12 + 2 * ncls);
   MSL_LAUNCH_CHECK();
@@ -1151,7 +1151,7 @@ int msl_head_grad_pack_batch(const float* dlocs, const float* dscores, float* co
     b.dO[k] = dO_pad[j]; b.D[k] = D[j]; b.H[k] = H[j]; b.W[k] = W[j]; b.prior_off[k] = prior_off[j];
     smax = std::max(smax, D[j] * H[j] * W[j]);
   }
-  hipLaunchKernelGGL(head_grad_pack_batch_kernel, dim3(std::min(msl::cdiv(N * CO * smax, 256), 1024), n), dim3(256), 0,
+  MSL_LAUNCH(head_grad_pack_batch_kernel, dim3(std::min(msl::cdiv(N * CO * smax, 256), 1024), n), dim3(256), 0,
                      (hipStream_t)stream, dlocs, dscores, b, N, CO, Ptot, ncls, 12 + 2 * ncls);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1170,7 +1170,7 @@ static int head_bwd_data_impl(const float* dO_pad, const float* Wb, void* g_a, i
     const int cts = msl::cdiv(ctiles, gy);
     dim3 grid(S / 64, msl::cdiv(ctiles, cts), N);
 #define MSL_HB(W_, B_) \
-  hipLaunchKernelGGL((head_bwd_data_lds_kernel<W_, 1, B_>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, cts)
+  MSL_LAUNCH((head_bwd_data_lds_kernel<W_, 1, B_>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, cts)
     if (bf16_out) {
       if (lw == 16) MSL_HB(16, true); else if (lw == 8) MSL_HB(8, true); else MSL_HB(4, true);
     } else {
@@ -1182,11 +1182,11 @@ static int head_bwd_data_impl(const float* dO_pad, const float* Wb, void* g_a, i
   }
   dim3 grid(msl::cdiv(S, 32), msl::cdiv(C, 64), N);
   if (bf16_out) {
-    if (MT == 1) hipLaunchKernelGGL((head_bwd_data_kernel<1, true>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
-    else hipLaunchKernelGGL((head_bwd_data_kernel<2, true>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+    if (MT == 1) MSL_LAUNCH((head_bwd_data_kernel<1, true>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+    else MSL_LAUNCH((head_bwd_data_kernel<2, true>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
   } else {
-    if (MT == 1) hipLaunchKernelGGL((head_bwd_data_kernel<1, false>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
-    else hipLaunchKernelGGL((head_bwd_data_kernel<2, false>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+    if (MT == 1) MSL_LAUNCH((head_bwd_data_kernel<1, false>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
+    else MSL_LAUNCH((head_bwd_data_kernel<2, false>), grid, dim3(256), 0, st, dO_pad, Wb, g_a, C, D, H, W);
   }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1244,7 +1244,7 @@ static int head_bww_impl(const float* dO_pad, const void* a_pad, bool bf16_cl, f
   float* bias_slabs = workspace + (size_t)p.nblocks * (C / 16) * 27 * MT * 256;
   if (p.lds_w) {
 #define MSL_HW(W_, B_)                                                                                               \
-  hipLaunchKernelGGL((head_bww_lds_kernel<W_, 1, B_>), grid, dim3(256), 0, st, dO_pad, a_pad, workspace, bias_slabs, N, \
+  MSL_LAUNCH((head_bww_lds_kernel<W_, 1, B_>), grid, dim3(256), 0, st, dO_pad, a_pad, workspace, bias_slabs, N, \
                      C, D, p.bpw)
     if (bf16_cl) {
       if (p.lds_w == 16) MSL_HW(16, true); else if (p.lds_w == 8) MSL_HW(8, true); else MSL_HW(4, true);
@@ -1255,7 +1255,7 @@ static int head_bww_impl(const float* dO_pad, const void* a_pad, bool bf16_cl, f
   } else {
     const size_t lds = (size_t)10 * MT * 256 * sizeof(float);
 #define MSL_HG(M_, B_)                                                                                                  \
-  hipLaunchKernelGGL((head_bwd_weight_kernel<M_, B_>), grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, \
+  MSL_LAUNCH((head_bwd_weight_kernel<M_, B_>), grid, dim3(256), lds, st, dO_pad, a_pad, workspace, bias_slabs, N, C, \
                      D, H, W, p.steps)
     if (bf16_cl) {
       if (MT == 1) MSL_HG(1, true); else MSL_HG(2, true);
@@ -1267,10 +1267,10 @@ static int head_bww_impl(const float* dO_pad, const void* a_pad, bool bf16_cl, f
   MSL_LAUNCH_CHECK();
   if (!dloc_w) return MSL_OK;
   const int total = co_total * C * 27;
-  hipLaunchKernelGGL(head_bwd_weight_reduce_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, st, workspace,
+  MSL_LAUNCH(head_bwd_weight_reduce_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, st, workspace,
                      dloc_w, dcl_w, C, MT, p.nblocks, co_total);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(head_bias_reduce_kernel, dim3(1), dim3(64), 0, st, bias_slabs, dloc_b, dcl_b, 16 * MT, p.nblocks, co_total);
+  MSL_LAUNCH(head_bias_reduce_kernel, dim3(1), dim3(64), 0, st, bias_slabs, dloc_b, dcl_b, 16 * MT, p.nblocks, co_total);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -719,7 +719,7 @@ int msl_make_priors(float* out, int row_off, int D0, int D1, int D2, double scal
                     void* stream) {
   if (D0 <= 0 || D1 <= 0 || D2 <= 0 || boxes_per_location < 1) return MSL_ERR_ARG;
   const int total = D0 * D1 * D2 * boxes_per_location;
-  hipLaunchKernelGGL(make_priors_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out,
+  MSL_LAUNCH(make_priors_kernel, dim3(msl::cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, out,
                      row_off, D0, D1, D2, scale, boxes_per_location);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -729,7 +729,7 @@ int msl_make_priors(float* out, int row_off, int D0, int D1, int D2, double scal
 int msl_box_transform(const float* boxes, const float* priors, float* out, int n, int op, void* stream) {
   if (n < 0 || op < 0 || op > 3) return MSL_ERR_ARG;
   if (n == 0) return MSL_OK;
-  hipLaunchKernelGGL(box_transform_kernel, dim3(msl::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, boxes, priors,
+  MSL_LAUNCH(box_transform_kernel, dim3(msl::cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, boxes, priors,
                      out, n, op);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -739,7 +739,7 @@ int msl_iou_matrix(const float* set1, const float* set2, float* out, int n1, int
                    void* stream) {
   if (n1 < 0 || n2 < 0) return MSL_ERR_ARG;
   if (n1 == 0 || n2 == 0) return MSL_OK;
-  hipLaunchKernelGGL(iou_matrix_kernel, dim3(msl::cdiv(n2, 256), n1), dim3(256), 0, (hipStream_t)stream, set1, set2,
+  MSL_LAUNCH(iou_matrix_kernel, dim3(msl::cdiv(n2, 256), n1), dim3(256), 0, (hipStream_t)stream, set1, set2,
                      out, n1, n2, intersection_only);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -755,15 +755,15 @@ static int match_impl(const float* gt_boxes, const long long* gt_labels, const i
   hipStream_t st = (hipStream_t)stream;
   dim3 gp(msl::cdiv(P, 256), N);
   if (total_objects > 0) {
-    hipLaunchKernelGGL(match_prior_best_kernel, gp, dim3(256), 0, st, gt_boxes, obj_off, priors_c, overlap, obj, P, npos);
+    MSL_LAUNCH(match_prior_best_kernel, gp, dim3(256), 0, st, gt_boxes, obj_off, priors_c, overlap, obj, P, npos);
     MSL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_object_best_kernel, dim3(total_objects), dim3(MOB_T), 0, st, gt_boxes, priors_c,
+    MSL_LAUNCH(match_object_best_kernel, dim3(total_objects), dim3(MOB_T), 0, st, gt_boxes, priors_c,
                        prior_for_obj, P);
     MSL_LAUNCH_CHECK();
-    hipLaunchKernelGGL(match_force_kernel, dim3(N), dim3(256), 0, st, obj_off, prior_for_obj, overlap, obj, P);
+    MSL_LAUNCH(match_force_kernel, dim3(N), dim3(256), 0, st, obj_off, prior_for_obj, overlap, obj, P);
     MSL_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(match_encode_kernel, gp, dim3(256), 0, st, gt_boxes, gt_labels, obj_off, priors_c, overlap, obj,
+  MSL_LAUNCH(match_encode_kernel, gp, dim3(256), 0, st, gt_boxes, gt_labels, obj_off, priors_c, overlap, obj,
                      thr_lo, thr_hi, soft, true_classes, true_locs, matched, P, npos, total_objects > 0 ? 0 : 1);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -795,10 +795,10 @@ int msl_multibox_loss_fwd(const float* locs, const float* scores, const long lon
                           void* stream) {
   if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
+  MSL_LAUNCH(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
                      true_locs, workspace, N * P, ncls, (int*)nullptr);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(multibox_loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, LOSS_BLOCKS, loss_out);
+  MSL_LAUNCH(multibox_loss_finalize_kernel, dim3(1), dim3(64), 0, st, workspace, LOSS_BLOCKS, loss_out);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -808,7 +808,7 @@ int msl_multibox_loss_bwd(const float* locs, const float* scores, const long lon
                           const float* true_locs, const float* loss_out, const float* upstream, float* dlocs,
                           float* dscores, int N, int P, int ncls, void* stream) {
   if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(multibox_loss_bwd_kernel<false>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream,
+  MSL_LAUNCH(multibox_loss_bwd_kernel<false>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream,
                      locs, scores, true_classes, true_locs, const_cast<float*>(loss_out), nullptr, 0, upstream, dlocs,
                      dscores, N * P, ncls);
   MSL_LAUNCH_CHECK();
@@ -822,10 +822,10 @@ int msl_multibox_loss_fwd_bwd(const float* locs, const float* scores, const long
                               float* dlocs, float* dscores, int* nan_flag, int N, int P, int ncls, void* stream) {
   if (N <= 0 || P <= 0 || ncls < 2 || ncls > MAXC) return MSL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
+  MSL_LAUNCH(multibox_loss_partial_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
                      true_locs, workspace, N * P, ncls, nan_flag);
   MSL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(multibox_loss_bwd_kernel<true>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores,
+  MSL_LAUNCH(multibox_loss_bwd_kernel<true>, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, st, locs, scores,
                      true_classes, true_locs, loss_out, workspace, LOSS_BLOCKS, upstream, dlocs, dscores, N * P, ncls);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -851,7 +851,7 @@ int msl_multibox_loss_pack(const float* locs, const float* scores, const long lo
     dst.prior_off[k] = prior_off[k];
   }
   const int CO = 16 * ((12 + 2 * ncls + 15) / 16);
-  hipLaunchKernelGGL(multibox_loss_pack_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream, locs, scores,
+  MSL_LAUNCH(multibox_loss_pack_kernel, dim3(msl::cdiv(N * P, 256)), dim3(256), 0, (hipStream_t)stream, locs, scores,
                      true_classes, true_locs, npos, upstream, partials, nan_flag, dst, n, N, P, ncls, CO);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -874,15 +874,15 @@ int msl_multibox_loss_var(const float* locs, const float* scores, const long lon
   hipStream_t st = (hipStream_t)stream;
   float* sel = (float*)var_ws;
   double* sums = (double*)((char*)var_ws + (((size_t)N * P * sizeof(float) + 15) & ~(size_t)15));
-  hipLaunchKernelGGL(multibox_loss_partial_var_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
+  MSL_LAUNCH(multibox_loss_partial_var_kernel, dim3(LOSS_BLOCKS), dim3(256), 0, st, locs, scores, true_classes,
                      true_locs, workspace, sel, N * P, ncls, flags, nan_flag);
   MSL_LAUNCH_CHECK();
   if (flags & VAR_HNM) {
-    hipLaunchKernelGGL(multibox_hnm_select_kernel, dim3(N), dim3(1024), 0, st, true_classes, sel, sums, P, neg_pos_ratio);
+    MSL_LAUNCH(multibox_hnm_select_kernel, dim3(N), dim3(1024), 0, st, true_classes, sel, sums, P, neg_pos_ratio);
     MSL_LAUNCH_CHECK();
   }
   const int write = dlocs != nullptr;
-  hipLaunchKernelGGL(multibox_loss_bwd_var_kernel, dim3(write ? msl::cdiv(N * P, 256) : 1), dim3(256), 0, st, locs,
+  MSL_LAUNCH(multibox_loss_bwd_var_kernel, dim3(write ? msl::cdiv(N * P, 256) : 1), dim3(256), 0, st, locs,
                      scores, true_classes, true_locs, loss_out, workspace, LOSS_BLOCKS, sums, N, sel, upstream, dlocs,
                      dscores, N * P, ncls, flags, write);
   MSL_LAUNCH_CHECK();

@@ -204,12 +204,17 @@ __global__ __launch_bounds__(256) void nan_flag_kernel(const float* __restrict__
 
 }  // namespace
 
+msl::StopEventArm& msl::stop_event_arm() {
+  static thread_local msl::StopEventArm arm;
+  return arm;
+}
+
 extern "C" {
 
 int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp,
                   const unsigned char* is_bias, int n, void* stream) {
   if (n <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(adam_kernel, dim3(min(msl::cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, params,
+  MSL_LAUNCH(adam_kernel, dim3(min(msl::cdiv(n, 256), 2048)), dim3(256), 0, (hipStream_t)stream, params,
                      grads, exp_avg, exp_avg_sq, hp, is_bias, n);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -240,7 +245,7 @@ int msl_grad_reduce_table_set(void* host_table, int index, int first_block, int 
 
 int msl_grad_reduce_batch(const void* table, int n_entries, int total_blocks, void* stream) {
   if (!table || n_entries <= 0 || n_entries > 64 || total_blocks <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(grad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+  MSL_LAUNCH(grad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                      (const GradReduceEntry*)table, n_entries, (const int*)nullptr);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -250,7 +255,7 @@ int msl_grad_reduce_batch(const void* table, int n_entries, int total_blocks, vo
 // msl_grad_reduce_table_set returned): the workgroups then do not search the table
 int msl_grad_reduce_batch_indexed(const void* table, int n_entries, const int* block_entry, int total_blocks, void* stream) {
   if (!table || !block_entry || n_entries <= 0 || n_entries > 64 || total_blocks <= 0) return MSL_ERR_ARG;
-  hipLaunchKernelGGL(grad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
+  MSL_LAUNCH(grad_reduce_batch_kernel, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream,
                      (const GradReduceEntry*)table, n_entries, block_entry);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -260,7 +265,7 @@ int msl_grad_reduce_batch_indexed(const void* table, int n_entries, const int* b
 int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream) {
   if (n == 0) return MSL_OK;
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
-  hipLaunchKernelGGL(nan_flag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, flag, bit);
+  MSL_LAUNCH(nan_flag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, flag, bit);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -307,6 +312,22 @@ int msl_event_record(void* ev, void* stream) { return (int)hipEventRecord((hipEv
 int msl_stream_wait_event(void* stream, void* ev) {
   return (int)hipStreamWaitEvent((hipStream_t)stream, (hipEvent_t)ev, 0);
 }
+
+// ---- stop events: a fork without a record packet (common.hpp, MSL_LAUNCH) ---------------------------------------------------
+// msl_arm_stop_event(ev, skip): the (skip + 1)-th kernel launch this THREAD issues from now on completes `ev` (as if
+// msl_event_record(ev, that launch's stream) followed it).  The caller must know how many kernels the entry points in
+// between launch: msl_thread_launch_count() before and after a call tells (the launch-program recorder does that).
+int msl_arm_stop_event(void* ev, int skip) {
+  if (ev == nullptr || skip < 0) return MSL_ERR_ARG;
+  msl::StopEventArm& a = msl::stop_event_arm();
+  if (a.ev != nullptr) return MSL_ERR_ARG;  // the previous arming was never consumed: a miscounted program
+  a.ev = (hipEvent_t)ev;
+  a.skip = skip;
+  return MSL_OK;
+}
+// 1 if an armed stop event is still waiting for its launch (after the entry point it was meant for: a bug)
+int msl_stop_event_pending(void) { return msl::stop_event_arm().ev != nullptr ? 1 : 0; }
+int msl_thread_launch_count(void) { return (int)(msl::stop_event_arm().launches & 0x7FFFFFFFu); }
 
 int msl_abi_version(void) { return 1; }
 

@@ -617,7 +617,7 @@ static int launch_strip(const float* X, const float* in_scale, const float* in_s
                         double* partials, int N, int M, int K, int S, int cols, const msl::BnFold& fold, hipStream_t st) {
   dim3 grid(S / cols, N);
 #define MSL_ST(K_, C_, MT_) \
-  hipLaunchKernelGGL((pw_strip_kernel<K_, C_, MT_, AFFINE, STATS, TRANS_W>), grid, dim3(256), 0, st, X, in_scale, in_shift, Wt, Y, partials, S, fold)
+  MSL_LAUNCH((pw_strip_kernel<K_, C_, MT_, AFFINE, STATS, TRANS_W>), grid, dim3(256), 0, st, X, in_scale, in_shift, Wt, Y, partials, S, fold)
   if (K == 32 && M == 64) MSL_ST(32, 256, 2);
   else if (K == 64 && M == 32) MSL_ST(64, 128, 1);
   else if (K == 64 && M == 128) MSL_ST(64, 64, 4);
@@ -652,13 +652,13 @@ template <bool AFFINE, bool STATS, bool TRANS_W>
 static int launch_wave(const float* X, const float* in_scale, const float* in_shift, const float* Wt, float* Y,
                        double* partials, int N, int M, int K, int S, const msl::BnFold& fold, hipStream_t st) {
 #define MSL_WV(KW_, MT_, NWK_)                                                                                        \
-  hipLaunchKernelGGL((pw_wave_kernel<KW_, MT_, AFFINE, STATS, TRANS_W, NWK_>),                                        \
+  MSL_LAUNCH((pw_wave_kernel<KW_, MT_, AFFINE, STATS, TRANS_W, NWK_>),                                        \
                      dim3(msl::cdiv(S, NWK_ == 1 ? 128 : 32), M / (32 * MT_), N), dim3(NWK_ == 1 ? 256 : NWK_ * 64), \
                      0, st, X, in_scale, in_shift, Wt, Y, partials, M, K, S, fold)
 #define MSL_WV1(KW_, MT_)                                                                                              \
   do {                                                                                                                 \
     if (nt == 2)                                                                                                       \
-      hipLaunchKernelGGL((pw_wave_kernel<KW_, MT_, AFFINE, STATS, TRANS_W, 1, 2>), dim3(msl::cdiv(S, 256), M / (32 * MT_), N), \
+      MSL_LAUNCH((pw_wave_kernel<KW_, MT_, AFFINE, STATS, TRANS_W, 1, 2>), dim3(msl::cdiv(S, 256), M / (32 * MT_), N), \
                          dim3(256), 0, st, X, in_scale, in_shift, Wt, Y, partials, M, K, S, fold);                     \
     else                                                                                                               \
       MSL_WV(KW_, MT_, 1);                                                                                             \
@@ -1043,10 +1043,10 @@ static int pwconv_fwd_impl(const float* z, const float* in_scale, const float* i
       hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(pw_gemm_ksplit_kernel<A_, S_, T_, 8>),    \
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                  \
       if (e_ != hipSuccess) return (int)e_;                                                                        \
-      hipLaunchKernelGGL((pw_gemm_ksplit_kernel<A_, S_, T_, 8>), g2, dim3(512), lds_, st, X_, in_scale, in_shift,  \
+      MSL_LAUNCH((pw_gemm_ksplit_kernel<A_, S_, T_, 8>), g2, dim3(512), lds_, st, X_, in_scale, in_shift,  \
                          Wp_, Y_, P_, M_, K_, S, fold);                                                            \
     } else {                                                                                                       \
-      hipLaunchKernelGGL((pw_gemm_ksplit_kernel<A_, S_, T_, 4>), g2, dim3(256),                                    \
+      MSL_LAUNCH((pw_gemm_ksplit_kernel<A_, S_, T_, 4>), g2, dim3(256),                                    \
                          (size_t)4 * KS_WAVE_LDS * sizeof(float), st, X_, in_scale, in_shift, Wp_, Y_, P_, M_, K_, S, fold); \
     }                                                                                                              \
   } while (0)
@@ -1062,11 +1062,11 @@ static int pwconv_fwd_impl(const float* z, const float* in_scale, const float* i
   }
   dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cout, BM), N);
   if (in_scale || fold.partials) {
-    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<true, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
-    else hipLaunchKernelGGL((pw_gemm_kernel<true, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
+    if (partials) MSL_LAUNCH((pw_gemm_kernel<true, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
+    else MSL_LAUNCH((pw_gemm_kernel<true, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
   } else {
-    if (partials) hipLaunchKernelGGL((pw_gemm_kernel<false, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
-    else hipLaunchKernelGGL((pw_gemm_kernel<false, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
+    if (partials) MSL_LAUNCH((pw_gemm_kernel<false, true, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
+    else MSL_LAUNCH((pw_gemm_kernel<false, false, false>), grid, dim3(256), 0, st, z, in_scale, in_shift, w, y, partials, Cout, Cin, S, fold);
   }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1107,7 +1107,7 @@ int msl_pwconv_bwd_data(const float* dy, const float* w, float* g_in, int N, int
     return MSL_OK;
   }
   dim3 grid(msl::cdiv(S, BN), msl::cdiv(Cin, BM), N);
-  hipLaunchKernelGGL((pw_gemm_kernel<false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
+  MSL_LAUNCH((pw_gemm_kernel<false, false, true>), grid, dim3(256), 0, (hipStream_t)stream, dy, nullptr,
                      nullptr, w, g_in, nullptr, Cin, Cout, S, pw_nofold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1137,7 +1137,7 @@ int msl_pwconv_bwd_weight_slabs(const float* dy, const float* z, const float* in
   if (bww_wave_plan(N, Cin, Cout, S, wp)) {
     dim3 grid(wp.ksplit, wp.tiles);
 #define MSL_BWW(MT_, A_)                                                                                          \
-  hipLaunchKernelGGL((pw_bww_wave_kernel<MT_, A_>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, \
+  MSL_LAUNCH((pw_bww_wave_kernel<MT_, A_>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, \
                      S, wp.chunks_per_img, wp.total_chunks, wp.chunks_per_block)
     if (wp.mt == 2) {
       if (in_scale) MSL_BWW(2, true); else MSL_BWW(2, false);
@@ -1152,11 +1152,11 @@ int msl_pwconv_bwd_weight_slabs(const float* dy, const float* z, const float* in
   BwPlan p = bw_plan(N, Cin, Cout, S);
   dim3 grid(p.ksplit, (Cout / 64) * (Cin / p.bnn));
   if (p.bnn == 64) {
-    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<64, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
-    else hipLaunchKernelGGL((pw_bwd_weight_kernel<64, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    if (in_scale) MSL_LAUNCH((pw_bwd_weight_kernel<64, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    else MSL_LAUNCH((pw_bwd_weight_kernel<64, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
   } else {
-    if (in_scale) hipLaunchKernelGGL((pw_bwd_weight_kernel<32, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
-    else hipLaunchKernelGGL((pw_bwd_weight_kernel<32, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    if (in_scale) MSL_LAUNCH((pw_bwd_weight_kernel<32, true>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
+    else MSL_LAUNCH((pw_bwd_weight_kernel<32, false>), grid, dim3(256), 0, st, dy, z, in_scale, in_shift, out, Cout, Cin, S, N, p.chunks_per_img, p.chunks_per_block);
   }
   MSL_LAUNCH_CHECK();
   return MSL_OK;
@@ -1192,7 +1192,7 @@ int msl_pwconv_bwd_weight_slabs_batch(const float* const* dy, const float* const
     b.dY[k] = b.Z[k] = b.in_scale[k] = b.in_shift[k] = nullptr; b.out[k] = nullptr;
     b.Cout[k] = b.Cin[k] = b.S[k] = b.chunks_per_img[k] = b.total_chunks[k] = b.chunks_per_block[k] = 0; b.ksplit[k] = 1;
   }
-  hipLaunchKernelGGL(pw_bww_wave_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b, n);
+  MSL_LAUNCH(pw_bww_wave_batch_kernel, dim3(total), dim3(256), 0, (hipStream_t)stream, b, n);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }
@@ -1206,7 +1206,7 @@ int msl_pwconv_bwd_weight(const float* dy, const float* z, const float* in_scale
   const int rc = msl_pwconv_bwd_weight_slabs(dy, z, in_scale, in_shift, workspace, N, Cin, Cout, S, stream);
   if (rc != MSL_OK) return rc;
   const int count = Cout * Cin;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(msl::cdiv(count, 32)), dim3(256), 0, (hipStream_t)stream, workspace, dw,
+  MSL_LAUNCH(slab_reduce_kernel, dim3(msl::cdiv(count, 32)), dim3(256), 0, (hipStream_t)stream, workspace, dw,
                      count, nslabs);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

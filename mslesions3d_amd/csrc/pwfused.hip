@@ -271,7 +271,7 @@ int msl_pwconv_bwd_fused(const float* g_y, const float* y, const float* bn_y_vec
   const size_t smem = ((size_t)(K + 2 * M) * (COLS + 1) + 4 * K + 4 * M) * sizeof(float);
   auto k = pw_bwd_fused_kernel<K, M, COLS>;
   if (smem > 64 * 1024) (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-  hipLaunchKernelGGL(k, dim3(wgs), dim3(512), smem, (hipStream_t)stream, g_y, y, bn_y_vec, y_partials, y_np, y_count, dgamma_y,
+  MSL_LAUNCH(k, dim3(wgs), dim3(512), smem, (hipStream_t)stream, g_y, y, bn_y_vec, y_partials, y_np, y_count, dgamma_y,
                      dbeta_y, w, z, bn_z_vec, g_z, z_partials, dw_slabs, S, S / COLS, N * (S / COLS));
   MSL_LAUNCH_CHECK();
   return MSL_OK;

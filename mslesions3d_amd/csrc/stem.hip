@@ -1187,7 +1187,7 @@ static int stem_fwd_impl(const float* x, const float* w, void* y, double* partia
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
       if (e_ != hipSuccess) return (int)e_;                                                                             \
     }                                                                                                                   \
-    hipLaunchKernelGGL((stem_fwd_rows_kernel<CI, B_>), grid, dim3(256), lds, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, \
+    MSL_LAUNCH((stem_fwd_rows_kernel<CI, B_>), grid, dim3(256), lds, st, x, w, y, partials, D, H, W, OD, OH, OW, sd, \
                        sh, chunks_per_row, chunks_per_n, iters);                                                        \
   } while (0)
     if (Cin == 1) { if (bf16_out) MSL_STEM_FR(1, true); else MSL_STEM_FR(1, false); }
@@ -1199,10 +1199,10 @@ static int stem_fwd_impl(const float* x, const float* w, void* y, double* partia
 #define MSL_STEM_FW(CI)                                                                                                 \
   do {                                                                                                                  \
     if (bf16_out)                                                                                                       \
-      hipLaunchKernelGGL((stem_fwd_mfma_kernel<CI, true>), grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, \
+      MSL_LAUNCH((stem_fwd_mfma_kernel<CI, true>), grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, OW, \
                          sd, sh, sw, chunks_per_row, chunks_per_n, iters);                                              \
     else                                                                                                                \
-      hipLaunchKernelGGL((stem_fwd_mfma_kernel<CI, false>), grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, \
+      MSL_LAUNCH((stem_fwd_mfma_kernel<CI, false>), grid, dim3(256), 0, st, x, w, y, partials, D, H, W, OD, OH, \
                          OW, sd, sh, sw, chunks_per_row, chunks_per_n, iters);                                          \
   } while (0)
   switch (Cin) {
@@ -1327,7 +1327,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)tl);                      \
       if (e_ != hipSuccess) return (int)e_;                                                                          \
     }                                                                                                                \
-    hipLaunchKernelGGL((stem_bww_tile_kernel<CI, B_, NW_>), dim3(nb), dim3(NW_ * 64), tl, st, (const void*)dy,       \
+    MSL_LAUNCH((stem_bww_tile_kernel<CI, B_, NW_>), dim3(nb), dim3(NW_ * 64), tl, st, (const void*)dy,       \
                        (const void*)yraw, x, workspace, N, D, H, OD, OH, tiles_total, it, bnv, w1);                  \
   } while (0)
 #define MSL_STEM_BWT(CI, B_)                          \
@@ -1341,7 +1341,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
 #undef MSL_STEM_BWT2
     MSL_LAUNCH_CHECK();
     if (!dw) return MSL_OK;
-    hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw,
+    MSL_LAUNCH(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw,
                        Cin * 27, NT, nb);
     MSL_LAUNCH_CHECK();
     return MSL_OK;
@@ -1353,7 +1353,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e_ != hipSuccess) return (int)e_;                                                                          \
     }                                                                                                                \
-    hipLaunchKernelGGL((stem_bwd_weight_kernel<CI, AP>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, D,  \
+    MSL_LAUNCH((stem_bwd_weight_kernel<CI, AP>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, D,  \
                        H, W, OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters, yraw, bnv, w1, fs);        \
   } while (0)
 #define MSL_STEM_BW1B(CI, AP)                                                                                        \
@@ -1363,7 +1363,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                     \
       if (e_ != hipSuccess) return (int)e_;                                                                          \
     }                                                                                                                \
-    hipLaunchKernelGGL((stem_bwd_weight_kernel<CI, AP, true>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, \
+    MSL_LAUNCH((stem_bwd_weight_kernel<CI, AP, true>), dim3(nblocks), dim3(256), lds, st, dy, x, workspace, N, \
                        D, H, W, OD, OH, OW, sd, sh, sw, chunks_per_row, total_chunks, iters, yraw, bnv, w1, fs);     \
   } while (0)
 #define MSL_STEM_BW(CI)                                \
@@ -1389,7 +1389,7 @@ static int stem_bww_impl(const float* dy, const float* x, float* dw, float* work
   MSL_LAUNCH_CHECK();
   if (!dw) return MSL_OK;  // deferred: the caller folds the slabs with msl_grad_reduce_batch (kind 2)
   const int K = Cin * 27;
-  hipLaunchKernelGGL(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw, K,
+  MSL_LAUNCH(stem_bwd_weight_reduce_kernel, dim3(msl::cdiv(32 * 32 * NT, 32)), dim3(256), 0, st, workspace, dw, K,
                      NT, nblocks);
   MSL_LAUNCH_CHECK();
   return MSL_OK;

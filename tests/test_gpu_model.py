@@ -614,31 +614,35 @@ def test_unfenced_replay_matches_the_fenced_steps():
 
 
 @pytest.mark.parametrize("size,n,steps", [((64, 64, 64), 2, 40), ((128, 128, 128), 4, 12)])
-def test_device_scope_events_are_bit_identical_to_system_scope_events(size, n, steps):
-    """_lib.DEVICE_SCOPE_EVENTS: the fork / join events of a launch program without the system-scope fence
-    (hipEventDisableSystemFence) against ordinary events - a scheduling detail, so replayed training steps end at bit-identical
-    parameters and losses, and predict_step returns identical detections (a consumer that read stale data behind such an
-    event would show up here: every step is deterministic)."""
+def test_cheap_forks_are_bit_identical_to_plain_event_records(size, n, steps):
+    """_lib.DEVICE_SCOPE_EVENTS (fork / join events of a launch program without the system-scope fence:
+    hipEventDisableSystemFence) and _lib.STOP_EVENT_FORKS (launch + event record -> launch carrying the event as its stop
+    event: no record packet) against ordinary events and records - scheduling details, so replayed training steps end at
+    bit-identical parameters and losses and predict_step returns identical detections (a consumer that read stale data
+    behind such a fork would show up here: every step is deterministic)."""
     from mslesions3d_amd import _lib
     from mslesions3d_amd.trainer import FusedTrainer
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
     boxes, labels = detinit.make_gt(8, n, size)
     boxes, labels = [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels]
-    saved, out = _lib.DEVICE_SCOPE_EVENTS, []
+    saved, out = (_lib.DEVICE_SCOPE_EVENTS, _lib.STOP_EVENT_FORKS), []
     try:
-        for flag in (False, True, True):
-            _lib.DEVICE_SCOPE_EVENTS = flag
+        for dev_scope, stop_forks in [(False, False), (True, False), (False, True), (True, True), (True, True)]:
+            _lib.DEVICE_SCOPE_EVENTS, _lib.STOP_EVENT_FORKS = dev_scope, stop_forks
             m = hip_model(1, size, lr=1e-3, batch_size=n).train()
             tr = FusedTrainer(m)
             losses = [tr.step(x, boxes, labels)["loss"] for _ in range(steps)]
             p = torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu()
+            forks = [e["native"]["stop_event_forks"] for e in tr._programs.values() if "native" in e]
+            assert forks, "the steps after the first replay a compiled launch program"
             m.eval()
             m.min_score = 0.01
             dets = [m.predict_step({"img": x}) for _ in range(3)][-1]
-            out.append((losses, p, dets))
+            out.append((losses, p, dets, forks))
+            assert all((f > 0) == stop_forks for f in forks), (stop_forks, forks)
     finally:
-        _lib.DEVICE_SCOPE_EVENTS = saved
-    for losses, p, dets in out[1:]:
+        _lib.DEVICE_SCOPE_EVENTS, _lib.STOP_EVENT_FORKS = saved
+    for losses, p, dets, _ in out[1:]:
         assert losses == out[0][0]
         assert torch.equal(p, out[0][1])
         for u, v in zip(dets, out[0][2]):

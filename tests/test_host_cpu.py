@@ -104,3 +104,60 @@ def test_softmax_restatement_is_bit_exact(tmp_path):
     lib.run(x.ctypes.data_as(ctypes.c_void_p), 2 * 9344, 2, out.ctypes.data_as(ctypes.c_void_p))
     ref = torch.softmax(torch.from_numpy(x), dim=2).numpy()[..., 1].reshape(-1, 1)
     assert np.array_equal(out.view(np.uint32), np.ascontiguousarray(ref).view(np.uint32))
+
+
+def test_stop_event_fusion_of_launch_programs():
+    """_lib._fuse_stop_events: an event record whose predecessor on the same stream launched k >= 1 kernels becomes an
+    msl_arm_stop_event(ev, k - 1) in front of that entry; never across a hook, a wait, a launch-free entry, a timed launch,
+    or when a second record follows the same launch; the wait of the other lane then refers to the launch entry."""
+    from mslesions3d_amd import _lib
+
+    def fn(name):
+        f = lambda *a: 0
+        f.__name__ = name
+        return f
+
+    rec, wait = fn("msl_event_record"), fn("msl_stream_wait_event")
+    k1, k2, k0 = fn("msl_pwconv_fwd"), fn("msl_head_conv_fwd"), fn("msl_fill_u32")
+    A, B = 0x1000, 0x2000  # streams
+    prog = _lib.Program()
+    entries = [
+        ((k1, (1, 2, A), "a"), 1),        # 0: fused with record of ev 11
+        ((k1, (1, 2, B), "b"), 1),        # 1: other stream in between: does not matter
+        ((rec, (11, A), "event"), 0),     # -> arm(11, 0) in front of entry 0
+        ((wait, (B, 11), "event"), 0),
+        ((k2, (3, 4, A), "c"), 2),        # two launches: arm(12, 1)
+        ((rec, (12, A), "event"), 0),
+        ((rec, (13, A), "event"), 0),     # second record behind the same launch: stays a record
+        ((k0, (5, 6, A), "d"), 0),        # launches nothing (a memset): the record behind it stays
+        ((rec, (14, A), "event"), 0),
+        ((k1, (1, 2, A), "timed"), 1),    # timed launch: stays
+        ((rec, (15, A), "event"), 0),
+        ((k1, (1, 2, A), "e"), 1),
+        ((None, (lambda: None), "hook"), 0),
+        ((rec, (16, A), "event"), 0),     # across a hook: stays
+        ((k1, (1, 2, A), "f"), 1),
+        ((wait, (A, 11), "event"), 0),    # a wait between launch and record: stays
+        ((rec, (17, A), "event"), 0),
+    ]
+    for (f, a, t), n in entries:
+        prog.append((f, a, t) if f is not None else (None, a, t))
+        prog.nl.append(n)
+    flat = _lib._fuse_stop_events(prog, ("timed",))
+    names = [(e[0].__name__ if e[0] is not None else "hook", e[1] if e[0] is not None and e[0].__name__ in ("msl_arm_stop_event", "msl_event_record") else None) for e in flat]
+    arms = [a for nme, a in names if nme == "msl_arm_stop_event"]
+    recs = [a[0] for nme, a in names if nme == "msl_event_record"]
+    assert arms == [(11, 0), (12, 1)]
+    assert recs == [13, 14, 15, 16, 17]
+    assert names[0][0] == "msl_arm_stop_event" and names[1][0] == "msl_pwconv_fwd"          # arm sits right in front of its launch
+    i12 = names.index(("msl_arm_stop_event", (12, 1)))
+    assert names[i12 + 1][0] == "msl_head_conv_fwd"
+    assert flat[0][3] == A and flat[i12][3] == A                                              # the arm runs on the launch's lane
+    saved = _lib.STOP_EVENT_FORKS
+    try:
+        _lib.STOP_EVENT_FORKS = False
+        assert [e[0].__name__ for e in _lib._fuse_stop_events(prog, ()) if e[0] is not None] == [f.__name__ for (f, _, _), _ in entries if f is not None]
+    finally:
+        _lib.STOP_EVENT_FORKS = saved
+    plain = list(prog)  # a program without launch counts (not from the recorder): never fused
+    assert not any(e[0] is not None and e[0].__name__ == "msl_arm_stop_event" for e in _lib._fuse_stop_events(plain, ()))
