@@ -20,19 +20,33 @@ int main() {
   CK(hipMalloc(&a, 1 << 20)); CK(hipMalloc(&b, 1 << 20));
   hipStream_t sa, sb;
   CK(hipStreamCreateWithFlags(&sa, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&sb, hipStreamNonBlocking));
-  for (int mode = 0; mode < 5; ++mode) {
+  for (int mode = 0; mode < 8; ++mode) {
     std::vector<hipEvent_t> ev(N);
-    const unsigned fl = hipEventDisableTiming | ((mode == 2 || mode == 4) ? hipEventDisableSystemFence : 0);
+    // modes 5-7: JOIN cost - stream A waits, before every kernel, for an event of stream B that completed long ago
+    // (5: default event, 6: hipEventDisableSystemFence event, 7: stop event of B's kernel, device scope)
+    const unsigned fl = hipEventDisableTiming | ((mode == 2 || mode == 4 || mode >= 6) ? hipEventDisableSystemFence : 0);
     for (auto& e : ev) CK(hipEventCreateWithFlags(&e, fl));
     hipEvent_t t0, t1;
     CK(hipEventCreate(&t0)); CK(hipEventCreate(&t1));
     for (int rep = 0; rep < 3; ++rep) {
       CK(hipDeviceSynchronize());
       auto h0 = std::chrono::steady_clock::now();
+      if (mode >= 5) {
+        for (int i = 0; i < N; ++i) {
+          if (mode == 7) hipExtLaunchKernelGGL(spin, dim3(4), dim3(256), 0, sb, nullptr, ev[i], 0, b, 200);
+          else { hipLaunchKernelGGL(spin, dim3(4), dim3(256), 0, sb, b, 200); CK(hipEventRecord(ev[i], sb)); }
+        }
+        CK(hipStreamSynchronize(sb));
+      }
       CK(hipEventRecord(t0, sa));
       for (int i = 0; i < N; ++i) {
-        if (mode >= 3) hipExtLaunchKernelGGL(spin, dim3(256), dim3(256), 0, sa, nullptr, ev[i], 0, a, 2000);
-        else hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, sa, a, 2000);
+        if (mode >= 5) {
+          CK(hipStreamWaitEvent(sa, ev[i], 0));
+          hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, sa, a, 300);
+          continue;
+        }
+        if (mode >= 3) hipExtLaunchKernelGGL(spin, dim3(256), dim3(256), 0, sa, nullptr, ev[i], 0, a, 300);
+        else hipLaunchKernelGGL(spin, dim3(256), dim3(256), 0, sa, a, 300);
         if (mode == 1 || mode == 2) CK(hipEventRecord(ev[i], sa));
         if (mode >= 1) {
           CK(hipStreamWaitEvent(sb, ev[i], 0));
