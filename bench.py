@@ -46,6 +46,9 @@ def parse():
                     "scores near 0.5: every image then reaches the 10*top_k candidate cap, i.e. the NMS kernels do their maximum "
                     "work (a longer run of the reference's live loss first drives every prior to background - 2500 steps: one "
                     "placeholder box per volume, no NMS work at all)")
+    ap.add_argument("--infer-depth", type=int, default=2,
+                    help="--mode infer: batches in flight in LSSD3D.predict_batches (what predict.py uses); 1 = one predict_step "
+                         "(enqueue, synchronise, build the lists) after the other")
     ap.add_argument("--map-cases", type=int, default=8, help="infer mode: synthetic cases scored for mAP@0.1 / 0.5")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE",
                     help="set a schedule option of the engine / trainer / launch-program replayer for A/B runs, e.g. --opt "
@@ -194,8 +197,8 @@ def main_infer(args):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     nboxes = 0
-    for _ in range(args.steps):
-        out = model.predict_step({"img": buf})
+    # predict.py's loop: LSSD3D.predict_batches keeps `--infer-depth` batches in flight (1 = predict_step batch by batch)
+    for out in model.predict_batches(({"img": buf} for _ in range(args.steps)), depth=args.infer_depth):
         nboxes += sum(len(b) for b in out[0])
     torch.cuda.synchronize()
     if world > 1:

@@ -8,6 +8,7 @@ NIfTI overlays are not written (nibabel absent; out of scope)
 """
 import argparse
 import json
+import collections
 import os
 from os.path import join as pjoin
 
@@ -104,9 +105,16 @@ def predict_example(args):
     ds = dataset.predict_dataset
     mine = ShardSampler(len(ds), rank, world, shuffle=False).indices().tolist()
     records = []
-    for pos in mine:
-        batch = collate([ds[pos]])
-        boxes, labels, scores = model.predict_step(batch, 0)
+    queued = collections.deque()  # (position, batch) of the passes in flight: predict_batches yields results in order
+
+    def feed():
+        for pos in mine:
+            batch = collate([ds[pos]])
+            queued.append((pos, batch))
+            yield batch
+
+    for boxes, labels, scores in model.predict_batches(feed(), depth=2):
+        pos, batch = queued.popleft()
         records.append((pos, batch["subject"][0],
                         {"shape": tuple(batch["img"].shape[2:]), "boxes": boxes[0].cpu().numpy().tolist(),
                          "labels": labels[0].cpu().numpy().tolist(), "scores": scores[0].cpu().numpy().tolist(),

@@ -134,6 +134,34 @@ def test_map_on_synthetic_192_equals_the_oracle_and_bf16_is_close(weights):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_predict_batches_pipeline_equals_predict_step(dtype):
+    """LSSD3D.predict_batches (what predict.py and `bench.py --mode infer` loop over): with 1, 2 or 3 batches in flight the
+    results - per image boxes, labels, scores, in order - are exactly those of predict_step batch by batch, on batches that
+    differ (the pinned landing zones and the staging buffer are reused across passes) and for host and device inputs."""
+    from mslesions3d_amd.synth import make_batch_on_device
+    m = _model("trained")
+    m.compute_dtype = dtype
+    m.min_score, m.max_overlap, m.top_k = 0.05, KW["max_overlap"], KW["top_k"]
+    xs = [make_batch_on_device(BATCH, SIZE, torch.device(DEV), 1, seed=8100 + k)[0] for k in range(5)]
+    ref = [m.predict_step({"img": x}, k) for k, x in enumerate(xs)]
+    assert sum(len(b) for r in ref for b in r[0]) > 0, "no detections: nothing compared"
+    assert len({tuple(len(b) for b in r[0]) for r in ref}) > 1 or not all(torch.equal(ref[0][2][0], r[2][0]) for r in ref[1:]), \
+        "the batches must differ"
+    for depth, host in [(1, False), (2, False), (3, False), (2, True), (8, False)]:
+        batches = [{"img": x.cpu() if host else x} for x in xs]
+        got = list(m.predict_batches(iter(batches), depth=depth))
+        assert len(got) == len(ref)
+        for r, g in zip(ref, got):
+            for u, v in zip(r, g):
+                assert len(u) == len(v) == BATCH
+                for a, b in zip(u, v):
+                    assert torch.equal(a, b), (depth, host)
+    assert list(m.predict_batches(iter([]))) == []
+    m.train()  # not in eval mode: falls back to predict_step batch by batch (which runs the eager path)
+    m.eval()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_bench_infer_line(dtype):
     """`python bench.py --mode infer [--dtype bf16]`: ONE JSON line for configs[3] - volumes/s, kept boxes/s, mAP on synthetic
     cases, the roofline of its longest launch and the oracle's predict path as cpu_baseline (fp32: keep-lists equal)."""

@@ -1,5 +1,7 @@
 """Print one training step's kernel timeline from a rocprofv3 --kernel-trace CSV: per launch the queue, start offset,
-duration and the gap to the previous kernel on the same queue.  Usage: python tools/timeline.py <kernel_trace.csv> [step]"""
+duration and the gap to the previous kernel on the same queue.  Usage: python tools/timeline.py <kernel_trace.csv> [step]
+[first-kernel]: a step ends with the Adam kernel; with ``first-kernel`` (e.g. stem_fwd: inference passes) it starts at the
+kernel whose name contains that string instead."""
 import csv
 import re
 import sys
@@ -17,8 +19,12 @@ def main():
     which = int(sys.argv[2]) if len(sys.argv) > 2 else -2
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    ends = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
-    lo, hi = ends[which - 1] + 1, ends[which] + 1
+    if len(sys.argv) > 3:
+        starts = [i for i, r in enumerate(rows) if sys.argv[3] in r["Kernel_Name"]]
+        lo, hi = starts[which - 1], starts[which]
+    else:
+        ends = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"]]
+        lo, hi = ends[which - 1] + 1, ends[which] + 1
     step = rows[lo:hi]
     t0 = int(step[0]["Start_Timestamp"])
     last_end = {}
