@@ -510,6 +510,18 @@ __device__ __forceinline__ void head_block_origin(int b, int& d0, int& h0) {
   else if (W == 8) { d0 = b; h0 = 0; }
   else { d0 = 4 * b; h0 = 0; }
 }
+// The forward kernel tiles ANY map whose extents are multiples of the block's (W = 16: 1 x 4 x 16, W = 8: 1 x 8 x 8,
+// W = 4: 4 x 4 x 4 positions; e.g. the 24^3 / 12^3 maps of a 192^3 volume take the 8- and 4-wide blocks): block b ->
+// origin (d0, h0, w0), blocks ordered w-fastest.  For the cubic maps above this is head_block_origin.
+template <int W>
+__device__ __forceinline__ void head_block_origin_any(int b, int Hr, int Wr, int& d0, int& h0, int& w0) {
+  typedef HeadGeo<W> G;
+  const int nbw = Wr / W, nbh = Hr / G::RB;
+  const int bw = b % nbw, bh = (b / nbw) % nbh, bd = b / (nbw * nbh);
+  d0 = bd * (G::PD - 2);
+  h0 = bh * G::RB;
+  w0 = bw * W;
+}
 // position pb (0..63) of a block -> offset of its tap (0,0,0) corner inside the slab
 template <int W>
 __device__ __forceinline__ int head_block_off(int pb) {
@@ -531,9 +543,9 @@ template <int W, int MT, int CH = HEAD_FWD_CH>
 __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* __restrict__ a_pad, const float* __restrict__ Wf,
                                                                    const float* __restrict__ loc_b, const float* __restrict__ cl_b,
                                                                    float* __restrict__ locs, float* __restrict__ scores,
-                                                                   float* __restrict__ slabs, int C, int D, int Ptot,
-                                                                   int prior_off, int ncls, int co_total, int KSG) {
-  typedef HeadGeo<W> G;
+                                                                   float* __restrict__ slabs, int C, int D, int Hr, int Wr,
+                                                                   int Ptot, int prior_off, int ncls, int co_total, int KSG) {
+  typedef HeadGeo<W> G;  // W: the block's width; the map is D x Hr x Wr
   constexpr int NT = HEAD_FWD_NT;
   constexpr int SLAB = G::PD * G::PH * G::PW, NCG = CH / 4;
   constexpr int NS = (CH * SLAB + NT - 1) / NT;        // slab floats per thread and chunk
@@ -546,10 +558,10 @@ __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* 
   const int n = blockIdx.y, ksg = blockIdx.z, b = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, j = lane & 15, q = lane >> 4;
   const int tile = wv & 3, khalf = wv >> 2;
-  const int S = D * W * W, Hp = W + 2;
-  const size_t volp = (size_t)(D + 2) * Hp * Hp;
-  int d0, h0;
-  head_block_origin<W>(b, d0, h0);
+  const int S = D * Hr * Wr, Hp = Hr + 2, Wp = Wr + 2;
+  const size_t volp = (size_t)(D + 2) * Hp * Wp;
+  int d0, h0, w0;
+  head_block_origin_any<W>(b, Hr, Wr, d0, h0, w0);
   const int cpb = C / KSG, c_begin = ksg * cpb, nchunks = cpb / CH;
   // chunk-invariant staging offsets of this thread
   int goff[NS], loff[NS];
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* 
     const int e = tid + NT * i;
     const int ch = e / SLAB, r = e % SLAB;
     const int pd = r / (G::PH * G::PW), ph = (r / G::PW) % G::PH, pw = r % G::PW;
-    goff[i] = e < CH * SLAB ? (int)(ch * volp) + ((d0 + pd) * Hp + h0 + ph) * Hp + pw : -1;
+    goff[i] = e < CH * SLAB ? (int)(ch * volp) + ((d0 + pd) * Hp + h0 + ph) * Wp + w0 + pw : -1;
     loff[i] = ch * G::CS + r;
   }
   const float* abase = a_pad + ((size_t)n * C + c_begin) * volp;
@@ -625,7 +637,8 @@ __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* 
   if (khalf == 1) return;
 #pragma unroll
   for (int m = 0; m < MT; ++m) acc[m] += xch[(tile * MT + m) * 64 + lane];
-  const int P = b * 64 + tile * 16 + j;
+  const int pb = tile * 16 + j;
+  const int P = ((d0 + pb / (W * G::RB)) * Hr + h0 + (pb / W) % G::RB) * Wr + w0 + pb % W;
 #pragma unroll
   for (int m = 0; m < MT; ++m) {
     if (KSG == 1) {
@@ -893,6 +906,21 @@ inline int head_lds_w(int C, int D, int H, int W, int MT = 1) {
   return 0;
 }
 
+// the forward kernel's block width for N maps of D x H x W (0: the register-fed kernel).  Measured (tools/probes/
+// head_bw_sweep.sh, us, register-fed / 4- / 8- / 16-wide blocks): 16^3 x 4, C 128: 34.9 / 31.2 / 30.2 / 28.3; 8^3 x 4, C 256:
+// 14.0 / 13.3 / 12.8 / -; 12^3 x 2, C 512: 39.5 / 31.5 / - / -; 24^3 x 2, C 256: 101.4 / 98.0 / 104.6 / -; 32^3 x 1, C 128:
+// 54.4 / 56.7 / 60.9 / 57.2; 48^3 x 2, C 128: 313 / 345 / 377 / 358 - staging through LDS pays while the launch has too few
+// workgroups to hide the register-fed kernel's load latency by occupancy (under ~512 blocks of 64 positions).
+inline int head_fwd_lds_bw(int N, int C, int D, int H, int W, int MT = 1) {
+  if (MT != 1 || C % HEAD_FWD_CH != 0) return 0;
+  if (const int cubic = head_lds_w(C, D, H, W, MT)) return cubic;  // the training maps (16^3 / 8^3 / 4^3)
+  if ((long long)N * D * H * W / 64 >= 512) return 0;
+  if (W % 4 == 0 && H % 4 == 0 && D % 4 == 0) return 4;
+  if (W % 16 == 0 && H % 4 == 0) return 16;
+  if (W % 8 == 0 && H % 8 == 0) return 8;
+  return 0;
+}
+
 // =====================================================================================================================
 // bf16 activation path (csrc/bf16.hip): the head convolutions on v_mfma_f32_16x16x32_bf16.  The feature map is the bf16
 // CHANNELS-LAST zero-haloed copy (N, D+2, H+2, W+2, C) written by msl_bn_relu_materialize_bf16, so the B operand of a
@@ -1010,7 +1038,7 @@ inline HwPlan head_bw_plan(int N, int C, int D, int H, int W, int MT) {
 // K split of the forward kernel over workgroups (partial slabs + head_fwd_finalize_kernel)
 inline int head_fwd_ksg(int N, int C, int D, int H, int W, int MT) {
   const int S = D * H * W;
-  if (head_lds_w(C, D, H, W, MT)) {
+  if (head_fwd_lds_bw(N, C, D, H, W, MT)) {
     // about one workgroup per CU.  More (512, 768 for the forward / bwd-data / weight-gradient kernels: a second wave per SIMD to cover the
     // loop's LDS-read waits) was measured 0.5-1.5 % SLOWER on the step (tools/probes/r02_headwgs.sh): the extra staging and
     // partial slabs cost what the latency hiding gains
@@ -1097,14 +1125,14 @@ int msl_head_conv_fwd(const float* a_pad, const float* Wf, const float* loc_b, c
   const int S = D * H * W, MT = head_mt(ncls), co_total = 12 + 2 * ncls;
   const int ksg = head_fwd_ksg(N, C, D, H, W, MT);
   hipStream_t st = (hipStream_t)stream;
-  const int lw = head_lds_w(C, D, H, W, MT);
+  const int lw = head_fwd_lds_bw(N, C, D, H, W, MT);
   if (lw) {
     dim3 grid(S / 64, N, ksg);
 #define MSL_HF(W_, MT_)                                                                                              \
   do {                                                                                                               \
     const size_t smem = ((size_t)HEAD_FWD_CH * HeadGeo<W_>::CS + (size_t)(HEAD_FWD_CH / 4) * 27 * MT_ * 64) * sizeof(float); \
     MSL_LAUNCH((head_fwd_lds_kernel<W_, MT_>), grid, dim3(HEAD_FWD_NT), smem, st, a_pad, Wf, loc_b, cl_b, locs,  \
-                       scores, workspace, C, D, Ptot, prior_off, ncls, co_total, ksg);                                \
+                       scores, workspace, C, D, H, W, Ptot, prior_off, ncls, co_total, ksg);                          \
   } while (0)
     // (chunks of 32 channels - half the barriers, twice the MFMA time per prefetch - measured equal: 27.3 vs 28.0 us at 16^3)
     if (lw == 16) MSL_HF(16, 1); else if (lw == 8) MSL_HF(8, 1); else MSL_HF(4, 1);

@@ -549,9 +549,13 @@ def test_bn_forward_backward():
                                            (2, 128, (16, 16, 16), 2), (4, 256, (8, 8, 8), 2), (4, 512, (4, 4, 4), 2),
                                            (1, 16, (16, 16, 16), 2), (3, 48, (8, 8, 8), 2), (1, 32, (8, 4, 4), 2),
                                            (5, 16, (12, 8, 8), 2), (1, 32, (16, 16, 16), 3),
-                                           # the 192^3 inference maps (register-fed kernels; an LDS geometry with 48-position blocks was measured no faster)
+                                           # the 192^3 inference maps: the forward kernel tiles them with 8 x 8 / 4 x 4 x 4 blocks
+                                           # (bwd: register-fed kernels)
                                            (2, 128, (24, 24, 24), 2), (2, 256, (12, 12, 12), 2), (1, 16, (12, 12, 12), 2),
-                                           (1, 32, (5, 24, 24), 2)])
+                                           (1, 32, (5, 24, 24), 2),
+                                           # tiled forward on non-cubic maps: 16-wide blocks (W % 16, H % 4), 8 x 8 blocks, 4^3 blocks
+                                           (1, 32, (3, 8, 32), 2), (2, 16, (2, 16, 24), 2), (1, 48, (4, 8, 12), 2),
+                                           (1, 32, (3, 12, 48), 2), (1, 16, (8, 12, 4), 2)])
 def test_heads_fwd_bwd(N, C, dims, ncls):
     L = _lib.load()
     a = torch.relu(rnd(N, C, *dims, seed=30)).requires_grad_(True)

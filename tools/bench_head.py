@@ -9,7 +9,7 @@ from mslesions3d_amd import _lib  # noqa: E402
 from mslesions3d_amd._lib import ptr  # noqa: E402
 
 L = _lib.load()
-N, C, D, ncls = 4, int(os.environ.get("HEAD_C", "128")), int(os.environ.get("HEAD_D", "16")), 2
+N, C, D, ncls = int(os.environ.get("HEAD_N", "4")), int(os.environ.get("HEAD_C", "128")), int(os.environ.get("HEAD_D", "16")), 2
 dev = "cuda"
 S = D ** 3
 pad = torch.zeros((N, C, D + 2, D + 2, D + 2), device=dev)
@@ -43,6 +43,8 @@ def timeit(fn, reps=50):
 gf = 2.0 * N * S * C * 27 * 16 / 1e9
 t = timeit(lambda: _lib.call("msl_head_conv_fwd", ptr(pad), ptr(Wf), ptr(lb), ptr(cb), ptr(locs), ptr(scores), ptr(ws), N, C, D, D, D, P, 0, ncls, st))
 print(f"head fwd      {D}^3 x{N} C={C}: {t:6.1f} us  {gf / t * 1e3:6.1f} TFLOP/s")
+if os.environ.get("HEAD_FWD_ONLY"):
+    sys.exit(0)
 t = timeit(lambda: _lib.call("msl_head_conv_bwd_data", ptr(dO), ptr(Wb), ptr(ga), N, C, D, D, D, ncls, st))
 print(f"head bwd-data {D}^3 x{N} C={C}: {t:6.1f} us  {gf / t * 1e3:6.1f} TFLOP/s")
 t = timeit(lambda: _lib.call("msl_head_conv_bwd_weight", ptr(dO), ptr(pad), None, None, None, None, ptr(ws), N, C, D, D, D, ncls, st))
