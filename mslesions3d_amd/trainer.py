@@ -31,6 +31,9 @@ class FusedTrainer:
         # A HIP-graph capture of the same program works but replays at 1.76 ms/step against 1.01 ms (ROCm 7.2, round 2:
         # hipGraphLaunch of the 127-node three-stream graph alone holds the host for 1.1 ms), so there is no graph path.
         self.use_programs = True
+        # the upload of the optimiser's hyper-parameters waits for the previous step through an event of the launch program
+        # (a stop event of the Adam launch) instead of a torch wait_stream, which put a record at the head of the chain
+        self.hp_wait_event = True
         self._programs = collections.OrderedDict()  # LRU, at most max_programs entries (each pins its input tensors)
         self.max_programs = 16
         self._staging = {}         # (image shape, target capacity) -> persistent input buffers (see _stage)
@@ -108,6 +111,11 @@ class FusedTrainer:
         if red.active:
             _lib.record_hook(red.finish, tag="hook:finish")
         self.opt.step(grad_scale=scale, gather_autograd_grads=False)
+        if eng.multi_stream and eng.prologue_on_side:
+            # "the optimiser has read its hyper-parameter vector": what the NEXT step's upload of that vector waits for.  Part
+            # of the launch program (behind the Adam launch it is a stop event: no packet of its own), so that the next step
+            # need not put a record at the head of the chain
+            eng._record(pl, "step_done", main)
         return pl, st
 
     def _stage(self, images, gt_boxes, gt_labels, obj_off, total_objects):
@@ -209,7 +217,11 @@ class FusedTrainer:
                     # step: copy it on the heads stream, which the chain joins before the optimiser anyway, instead of in
                     # front of the stem (the stream first waits for the previous step's optimiser, which still reads it)
                     sH = eng.side_streams(dev)[0]
-                    sH.wait_stream(self._stream)
+                    done = pl.events.get("step_done") if self.hp_wait_event else None
+                    if done is not None:  # recorded by the previous step's program, right behind its optimiser launch
+                        eng._wait(sH.cuda_stream, done)
+                    else:
+                        sH.wait_stream(self._stream)
                     with torch.cuda.stream(sH):
                         self.opt.prepare_step(grad_scale=1.0 / red.world)
                 else:
