@@ -173,8 +173,10 @@ def main_infer(args):
     torch.manual_seed(970205)
     model = LSSD3D(n_classes=2, input_channels=args.channels, input_size=size, threshold=[0.1, 0.2], alpha=1.0, lr=1e-3,
                    batch_size=args.batch).to(dev).train()
+    from mslesions3d_amd import _lib
     # a short optimisation run so that scores and running statistics are not the initial ones (fp32, outside the timed region)
     tr = FusedTrainer(model)
+    opts = apply_opts(args.opt, model._engine, tr, _lib)  # (--opt used to be ignored in this mode)
     t_tr = time.perf_counter()
     for s in range(args.train_steps):
         x, boxes, labels = make_batch_on_device(args.batch, size, dev, args.channels, seed=5000 + s % 64)
@@ -271,8 +273,19 @@ def main_infer(args):
                          "frac_basis": f"HIP-event pair around the launch inside the timed predict passes, on every {args.event_every}. pass",
                          "traffic": None, "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_us": round(avg_ms * 1e3, 2),
                          "launches_timed": len(ms)},
-            "knobs": {k: v for k, v in sorted(os.environ.items()) if k.startswith("MSL_")},
+            "knobs": dict({k: v for k, v in sorted(os.environ.items()) if k.startswith("MSL_")}, **opts),
         }
+        if getattr(pl, "stem_dw_eval", False) and avg_ms:
+            # eval mode runs stem + BatchNorm + ReLU + block-1 depthwise convolution as ONE launch that never writes the stem
+            # activation (csrc/stemdw.hip): x and z1 are all it moves (85 MB at 192^3 x 2), so it is bound by the fp32 matrix
+            # pipe - algorithmic FLOPs (no recomputed halo) over the fp32 MFMA peak of MI355X_MICROARCH.md
+            d1 = pl.dims[1]
+            flops = 2.0 * 27 * args.channels * 32 * args.batch * vol(d0) + 2.0 * 27 * 32 * args.batch * vol(d1)
+            tf = flops / (avg_ms * 1e-3) / 1e12
+            out["roofline"].update({"bound": "mfma", "kernel": "stem + BatchNorm + ReLU + block-1 depthwise forward in one launch "
+                                    "(stem_dw_eval_kernel; the longest launch of the pass)", "achieved": round(tf, 2),
+                                    "peak": 157.3, "unit": "TFLOP/s", "frac": round(tf / 157.3, 4), "algorithmic_flops_per_launch": flops,
+                                    "algorithmic_bytes_per_launch": 4.0 * args.batch * args.channels * vol(size) + esz * args.batch * 32 * vol(d1)})
         if world == 1 and not args.no_cpu_baseline:
             cb, odet = cpu_baseline_infer(model, x, max(1, min(args.cpu_steps, 10)), kw)
             out["cpu_baseline"] = cb

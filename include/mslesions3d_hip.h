@@ -226,6 +226,17 @@ int msl_head_conv_bwd_weight(const float* dO_pad, const float* a_pad, float* dlo
  * and all accumulators stay fp32.  The forward kernels of the backbone + heads (mobilenet.py:26-49, ssd3d.py:113-169): */
 int msl_stem_conv_fwd_bf16(const float* x, const float* w, void* y_bf16, double* partials, int N, int Cin, int D,
                            int H, int W, int sd, int sh, int sw, void* stream);
+
+/* Eval-mode stem + block-1 depthwise convolution in one pass (inference; mobilenet.py:26-31 followed by the depthwise half of
+ * mobilenet.py:34-49): z1 (N,32,D/4,H/4,W/4) = dw3x3x3 s2 (wdw [32][27]) of relu(bn_scale * stem(x) + bn_shift), the stem
+ * activation never reaching HBM (in eval mode the BatchNorm between the two is a constant affine).  Values are those of
+ * msl_stem_conv_fwd followed by msl_dwconv_fwd, bit for bit.  _supported: 1 if the shape is taken (Cin <= 2, D, H, W multiples
+ * of 4, W/2 a multiple of 32 and <= 96), else callers use the two separate entry points. */
+int msl_stem_dw_fwd_eval_supported(int N, int Cin, int D, int H, int W);
+int msl_stem_dw_fwd_eval(const float* x, const float* w, const float* bn_scale, const float* bn_shift, const float* wdw,
+                         float* z, int N, int Cin, int D, int H, int W, void* stream);
+int msl_stem_dw_fwd_eval_bf16(const float* x, const float* w, const float* bn_scale, const float* bn_shift, const float* wdw,
+                              void* z_bf16, int N, int Cin, int D, int H, int W, void* stream);
 int msl_dwconv_fwd_bf16_num_partials(int N, int C, int D, int H, int W, int stride);
 /* the register-marching wave kernels of the fp32 path on bf16 storage (square power-of-two planes; MSL_ERR_UNSUPPORTED
  * otherwise - msl_dwconv_*_bf16 try these first and fall back to the LDS-tiled any-shape kernels) */

@@ -134,6 +134,9 @@ _SIGNATURES = {
     "msl_run_program": (_I, [_P, _P, _I, _I, _P]),
     "msl_run_program_mt": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),
     "msl_fill_u32": (_I, [_P, ctypes.c_uint, _Z, _P]),
+    "msl_stem_dw_fwd_eval_supported": (_I, [_I] * 5),
+    "msl_stem_dw_fwd_eval": (_I, [_P] * 6 + [_I] * 5 + [_P]),
+    "msl_stem_dw_fwd_eval_bf16": (_I, [_P] * 6 + [_I] * 5 + [_P]),
     "msl_event_create": (_I, [_P]),
     "msl_event_create_device": (_I, [_P]),
     "msl_arm_stop_event": (_I, [_P, _I]),

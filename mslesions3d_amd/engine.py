@@ -300,6 +300,8 @@ class Engine:
         self.finalize_on_side = True
         self.side_stream_priority = 0
         self.fuse_stem = True     # block-1 / stem backward without materialising dL/d(stem activation)
+        # eval mode: stem + block-1 depthwise convolution in one pass, the stem activation never in HBM (csrc/stemdw.hip)
+        self.fuse_stem_eval = True
         self.channel_link = True  # per-channel backward links of the tail blocks in one launch each (csrc/chanlink.hip)
         self.fuse_pw_bwd = True   # whole pointwise backward of the big early block in one pass (csrc/pwfused.hip)
         self.fuse_dw_bww = True   # depthwise weight gradient of a big stride-2 block inside its bwd-data pass
@@ -506,8 +508,14 @@ class Engine:
         # stem (features[0] = Conv3d + BN + ReLU)
         D, H, W = pl.in_dims
         sd, sh, sw = specs[0]["stride"]
-        self._k("stem_fwd", "msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]),
-                ptr(pl.part_y[0]) if training else None, N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
+        stem_dw = self._stem_dw_eval(specs, training, N, D, H, W)
+        if stem_dw:
+            self._k("stem_fwd", "msl_stem_dw_fwd_eval", ptr(x), ptr(feats[0][0].weight), ptr(pl.bn_y[0][0]), ptr(pl.bn_y[0][1]),
+                    ptr(feats[1].conv1.weight), ptr(pl.z[1]), N, specs[0]["cin"], D, H, W, st)
+        else:
+            self._k("stem_fwd", "msl_stem_conv_fwd", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]),
+                    ptr(pl.part_y[0]) if training else None, N, specs[0]["cin"], D, H, W, sd, sh, sw, st)
+        pl.stem_dw_eval = stem_dw
         od, oh, ow = pl.dims[0]
         def bn_done(bn, vec, part, NP, count, name, folded=None):
             if not training:
@@ -526,7 +534,9 @@ class Engine:
             S = D * H * W
             s = sp["stride"][0]
             bn_prev = feats[0][1] if i == 1 else feats[i - 1].bn2
-            if folds(pl.np_y[i - 1]):
+            if i == 1 and stem_dw:
+                pass  # z1 came with the stem
+            elif folds(pl.np_y[i - 1]):
                 self._k(f"dw_fwd{i}", "msl_dwconv_fwd_fold", ptr(pl.y[i - 1]), ptr(pl.part_y[i - 1]), pl.np_y[i - 1],
                         float(N * pd * ph * pw), ptr(bn_prev.weight), ptr(bn_prev.bias), bn_prev.eps, ptr(blk.conv1.weight),
                         ptr(pl.z[i]), ptr(pl.part_z[i]), N, sp["cin"], pd, ph, pw, s, st)
@@ -746,8 +756,14 @@ class Engine:
         later = []  # BatchNorms folded into their consumer: running statistics + backward vectors in ONE launch at the end
         ev_bn_done = None
         D, H, W = pl.in_dims
-        self._k("stem_fwd", "msl_stem_conv_fwd_bf16", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), part(pl.part_y[0]), N,
-                specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        stem_dw = self._stem_dw_eval(specs, training, N, D, H, W)
+        if stem_dw:
+            self._k("stem_fwd", "msl_stem_dw_fwd_eval_bf16", ptr(x), ptr(feats[0][0].weight), ptr(pl.bn_y[0][0]),
+                    ptr(pl.bn_y[0][1]), ptr(feats[1].conv1.weight), ptr(pl.z[1]), N, specs[0]["cin"], D, H, W, st)
+        else:
+            self._k("stem_fwd", "msl_stem_conv_fwd_bf16", ptr(x), ptr(feats[0][0].weight), ptr(pl.y[0]), part(pl.part_y[0]), N,
+                    specs[0]["cin"], D, H, W, *specs[0]["stride"], st)
+        pl.stem_dw_eval = stem_dw
         od, oh, ow = pl.dims[0]
         out_feats = {}
         for i in range(1, len(specs)):
@@ -763,7 +779,9 @@ class Engine:
                       and L.msl_dwconv_wave_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]) > 0)
             if training and not fold_y and (i - 1) not in pl.feat_ids:  # (a feature map's vectors exist already)
                 self._bn_fwd(bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev, True, st)
-            if fold_y:
+            if i == 1 and stem_dw:
+                pass  # z1 came with the stem
+            elif fold_y:
                 later.append((bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev))
                 self._k(f"dw_fwd{i}", "msl_dwconv_fwd_wave_bf16_fold", ptr(pl.y[i - 1]), ptr(pl.part_y[i - 1]), pl.np_y[i - 1],
                         float(cnt_prev), ptr(bn_prev.weight), ptr(bn_prev.bias), bn_prev.eps, ptr(blk.conv1.weight), ptr(pl.z[i]),
@@ -987,6 +1005,14 @@ class Engine:
         if not groups:  # single process: ONE reduction launch for every layer's partial sums, in front of the optimiser
             self._grad_reduce(pl, "all", None, st)
         report(0)
+
+    def _stem_dw_eval(self, specs, training, N, D, H, W):
+        """Eval mode: may the stem and block 1's depthwise convolution run as one launch (csrc/stemdw.hip)?"""
+        if training or not self.fuse_stem_eval or len(specs) < 2:
+            return False
+        if tuple(specs[0]["stride"]) != (2, 2, 2) or tuple(specs[1]["stride"]) != (2, 2, 2) or specs[0]["cout"] != 32:
+            return False
+        return bool(_lib.load().msl_stem_dw_fwd_eval_supported(N, specs[0]["cin"], D, H, W))
 
     def _finalize_all_beside(self, pl, bn_layers, st):
         """_finalize_all on the weight-gradient stream, ordered behind what ``st`` holds so far (the last pointwise

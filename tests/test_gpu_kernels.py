@@ -53,6 +53,9 @@ def stats_from_partials(part, C, NP):
     return p[0], p[1]
 
 
+BF_EPS = 2.0 ** -8  # half a bf16 ulp, relative
+
+
 def affine_act(x, sc, sh):
     return torch.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
 
@@ -916,3 +919,52 @@ def test_dw_s2_bwd_data_bnreduce_bww_matches_autograd(n, c, dims, acc):
     close(sums[1], bn.weight.grad, 2e-4, 1e-5 * float(bn.weight.grad.abs().max()), "sum gm * xhat (= dgamma)")
     dw = wp.view(c * 27, NP).sum(-1).float().view(c, 1, 3, 3, 3)
     close(dw, conv.weight.grad, 2e-4, 1e-5 * float(conv.weight.grad.abs().max()), "depthwise weight gradient")
+
+
+# ------------------------------------------------------------------------------------------------- fused eval stem + depthwise
+@pytest.mark.parametrize("N,cin,dims", [(2, 1, (64, 64, 64)),      # AW 32, four output rows per workgroup
+                                        (1, 1, (32, 48, 192)),     # AW 96 (the 192^3 inference rows), three rows, 1.5 chunks per row
+                                        (1, 2, (16, 24, 128)),     # two input channels, AW 64
+                                        (1, 1, (8, 8, 64)),        # two output rows per workgroup, two output planes
+                                        (3, 1, (12, 16, 64))])     # odd plane count per segment, several images
+@pytest.mark.parametrize("bf16", [False, True])
+def test_stem_dw_eval_fused_equals_the_two_launches(N, cin, dims, bf16):
+    """msl_stem_dw_fwd_eval[_bf16] (stem + BatchNorm affine + ReLU + block-1 depthwise convolution in one pass, the stem
+    activation never in HBM) returns what msl_stem_conv_fwd + msl_dwconv_fwd return, bit for bit, and the torch composition
+    within fp32 / bf16 tolerance."""
+    L = _lib.load()
+    assert L.msl_stem_dw_fwd_eval_supported(N, cin, *dims) == 1
+    x = rnd(N, cin, *dims, seed=1)
+    w = rnd(32, cin, 3, 3, 3, seed=2) / (27 * cin) ** 0.5
+    wd = rnd(32, 1, 3, 3, 3, seed=3) / 27 ** 0.5
+    sc, sh = rnd(32, seed=4).abs() + 0.5, rnd(32, seed=5, scale=0.3)
+    a_dims = tuple(d // 2 for d in dims)
+    z_dims = tuple(d // 4 for d in dims)
+    dt = torch.bfloat16 if bf16 else torch.float32
+    sfx = "_bf16" if bf16 else ""
+    y = torch.empty((N, 32) + a_dims, dtype=dt, device=DEV)
+    _lib.call("msl_stem_conv_fwd" + sfx, ptr(K(x)), ptr(K(w)), ptr(y), None, N, cin, *dims, 2, 2, 2, st())
+    z_ref = torch.full((N, 32) + z_dims, float("nan"), dtype=dt, device=DEV)
+    if bf16:
+        _lib.call("msl_dwconv_fwd_bf16", ptr(y), ptr(K(sc)), ptr(K(sh)), ptr(K(wd)), ptr(z_ref), None, N, 32, *a_dims, 2, st())
+    else:
+        _lib.call("msl_dwconv_fwd", ptr(y), ptr(K(sc)), ptr(K(sh)), ptr(K(wd)), ptr(z_ref), None, N, 32, *a_dims, 2, 0, st())
+    z = torch.full((N, 32) + z_dims, float("nan"), dtype=dt, device=DEV)
+    _lib.call("msl_stem_dw_fwd_eval" + sfx, ptr(K(x)), ptr(K(w)), ptr(K(sc)), ptr(K(sh)), ptr(K(wd)), ptr(z), N, cin, *dims, st())
+    assert not bool(torch.isnan(z.float()).any())
+    assert torch.equal(z, z_ref), float((z.float() - z_ref.float()).abs().max())
+    y0 = F.conv3d(x, w, stride=2, padding=1)
+    ref = F.conv3d(affine_act(y0, sc, sh), wd, stride=2, padding=1, groups=32)
+    if bf16:
+        close(z.float(), ref, 4 * BF_EPS, 2e-2, "fused stem+dw bf16")
+    else:
+        close(z, ref, 1e-4, 1e-5, "fused stem+dw")
+
+
+def test_stem_dw_eval_unsupported_shapes_are_refused():
+    L = _lib.load()
+    for N, cin, dims in [(1, 1, (30, 32, 64)), (1, 3, (32, 32, 64)), (1, 1, (32, 32, 96)), (1, 1, (32, 32, 256)), (0, 1, (32, 32, 64))]:
+        assert L.msl_stem_dw_fwd_eval_supported(N, cin, *dims) == 0, (N, cin, dims)
+    z = torch.zeros(1, device=DEV)
+    with pytest.raises(_lib.HipKernelError):
+        _lib.call("msl_stem_dw_fwd_eval", ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), ptr(z), 1, 1, 30, 32, 64, st())
