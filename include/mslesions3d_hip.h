@@ -397,6 +397,8 @@ int msl_detect_objects(const float* locs, const float* scores, const float* prio
 int msl_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* hp,
                   const unsigned char* is_bias, int n, void* stream);
 int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream);
+/* the same for two tensors in one launch: *flag |= bit_a if a holds a NaN, |= bit_b if b does */
+int msl_nan_flag2(const float* a, size_t na, int bit_a, const float* b, size_t nb, int bit_b, int* flag, void* stream);
 /* Batched gradient reduction (autograd's accumulation of the conv weight gradients, ssd3d.py:467-531 backward): the
  * weight-gradient kernels leave partial sums (fp32 slabs / fp64 partials) in their workspaces; ONE launch folds the
  * listed ones into the flat gradient arena in a fixed order.  The table is built on the host with _table_set (which

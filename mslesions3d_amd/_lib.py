@@ -130,6 +130,7 @@ _SIGNATURES = {
     "msl_detect_objects": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I] + [_P] * 15 + [_P]),
     "msl_adam_step": (_I, [_P, _P, _P, _P, _P, _P, _I, _P]),
     "msl_nan_flag": (_I, [_P, _Z, _P, _I, _P]),
+    "msl_nan_flag2": (_I, [_P, _Z, _I, _P, _Z, _I, _P, _P]),
     "msl_program_fn_id": (_I, [_P]),
     "msl_run_program": (_I, [_P, _P, _I, _I, _P]),
     "msl_run_program_mt": (_I, [_P, _P, _I, _I, _P, _P, _I, _P]),

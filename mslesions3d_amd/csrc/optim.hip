@@ -202,6 +202,16 @@ __global__ __launch_bounds__(256) void nan_flag_kernel(const float* __restrict__
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, bit);
 }
 
+// two tensors, one launch (the forward pass checks its two outputs: ssd3d.py:258-261)
+__global__ __launch_bounds__(256) void nan_flag2_kernel(const float* __restrict__ a, size_t na, int bit_a, const float* __restrict__ b,
+                                                        size_t nb, int bit_b, int* __restrict__ flag) {
+  bool bad_a = false, bad_b = false;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < na; i += (size_t)gridDim.x * 256) bad_a |= isnan(a[i]);
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nb; i += (size_t)gridDim.x * 256) bad_b |= isnan(b[i]);
+  const int bits = (__any(bad_a) ? bit_a : 0) | (__any(bad_b) ? bit_b : 0);
+  if (bits && (threadIdx.x & 63) == 0) atomicOr(flag, bits);
+}
+
 }  // namespace
 
 msl::StopEventArm& msl::stop_event_arm() {
@@ -266,6 +276,15 @@ int msl_nan_flag(const float* x, size_t n, int* flag, int bit, void* stream) {
   if (n == 0) return MSL_OK;
   const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
   MSL_LAUNCH(nan_flag_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, n, flag, bit);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+int msl_nan_flag2(const float* a, size_t na, int bit_a, const float* b, size_t nb, int bit_b, int* flag, void* stream) {
+  const size_t n = na > nb ? na : nb;
+  if (n == 0) return MSL_OK;
+  const int blocks = (int)((n + 255) / 256 < 1024 ? (n + 255) / 256 : 1024);
+  MSL_LAUNCH(nan_flag2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a, na, bit_a, b, nb, bit_b, flag);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -599,8 +599,7 @@ class Engine:
         if self.multi_stream:
             self._fork(pl, "fwd_heads_done", stH, st)
         if nan_check:  # the fused training step lets the loss kernel set the flag instead (it reads both tensors anyway)
-            _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
-            _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
+            _lib.call("msl_nan_flag2", ptr(pl.locs), pl.locs.numel(), 1, ptr(pl.scores), pl.scores.numel(), 2, ptr(pl.nan_flag), st)
         if want_features:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores
@@ -838,8 +837,7 @@ class Engine:
         if ms:
             self._fork(pl, "fwd_heads_done", stH, st)
         if nan_check:
-            _lib.call("msl_nan_flag", ptr(pl.locs), pl.locs.numel(), ptr(pl.nan_flag), 1, st)
-            _lib.call("msl_nan_flag", ptr(pl.scores), pl.scores.numel(), ptr(pl.nan_flag), 2, st)
+            _lib.call("msl_nan_flag2", ptr(pl.locs), pl.locs.numel(), 1, ptr(pl.scores), pl.scores.numel(), 2, ptr(pl.nan_flag), st)
         if want_features:
             return pl.locs, pl.scores, out_feats
         return pl.locs, pl.scores

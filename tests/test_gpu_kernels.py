@@ -166,6 +166,26 @@ def test_dw_fwd_eval_rows(N, C, dims, stride, affine):
     close(y2, y, 1e-6, 1e-6, "eval rows vs the training-mode kernel")
 
 
+@pytest.mark.parametrize("N,C,dims,stride", [(2, 512, (6, 6, 6), 1), (2, 7, (6, 6, 6), 2), (1, 5, (3, 5, 7), 1), (3, 3, (8, 8, 6), 2),
+                                             (1, 2, (1, 1, 1), 1), (1, 9, (5, 6, 14), 1)])
+@pytest.mark.parametrize("affine", [True, False])
+def test_dw_fwd_eval_small_maps(N, C, dims, stride, affine):
+    """Statistics-free forward of maps of at most 512 voxels that no wave / rows kernel takes (the 6^3 map of a 192^3 volume):
+    dw_small_eval_kernel equals the one-output-per-thread fallback bit for bit and torch's convolution to rounding."""
+    L = _lib.load()
+    x, w = rnd(N, C, *dims, seed=4), rnd(C, 1, 3, 3, 3, seed=5, scale=0.4)
+    sc, sh = rnd(C, seed=6).abs() + 0.5, rnd(C, seed=7, scale=0.3)
+    a = affine_act(x, sc, sh) if affine else x
+    ref = F.conv3d(a, w, stride=stride, padding=1, groups=C)
+    y = torch.full(ref.shape, float("nan"), device=DEV)
+    y_naive = torch.full(ref.shape, float("nan"), device=DEV)
+    for out, naive in ((y, 0), (y_naive, 1)):
+        _lib.call("msl_dwconv_fwd", ptr(K(x)), ptr(K(sc)) if affine else None, ptr(K(sh)) if affine else None,
+                  ptr(K(w)), ptr(out), None, N, C, *dims, stride, naive, st())
+    close(y, ref, 1e-5, 1e-5, "dw fwd (small map)")
+    assert torch.equal(y, y_naive)
+
+
 @pytest.mark.parametrize("N,C,dims,in_np,stride", [(2, 8, (16, 16, 16), 6, 1), (2, 8, (8, 8, 8), 100, 1),
                                                    (2, 32, (4, 4, 4), 70, 1), (1, 16, (5, 4, 4), 9, 1),
                                                    (2, 4, (6, 12, 16), 70, 1), (2, 16, (8, 8, 8), 70, 2),

@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/ks_$tag
 rocprofv3 --kernel-trace --stats -d /tmp/ks_$tag -o ks --output-format csv -- python3 "$root/bench.py" --mode infer --steps 40 --warmup 10 --no-cpu-baseline --map-cases 2 "$@" > "$out/ks.log" 2>&1
 cp "$(find /tmp/ks_$tag -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats.csv"
-python "$root/tools/timeline.py" "$(find /tmp/ks_$tag -name '*kernel_trace.csv' | head -1)" -2 stem_fwd > "$out/timeline.txt" 2>&1 || true
+python "$root/tools/timeline.py" "$(find /tmp/ks_$tag -name '*kernel_trace.csv' | head -1)" -2 stem_dw_eval > "$out/timeline.txt" 2>&1 || true
 n=0
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   name=$(echo $set | cut -d' ' -f1)
