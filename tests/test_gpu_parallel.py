@@ -186,3 +186,33 @@ def test_train_and_predict_entry_points_under_torchrun_two_ranks(tmp_path):
     assert names == sorted(os.path.basename(f) for f in glob.glob(str(out2 / "*"))) and len([n for n in names if n.endswith(".json")]) == 8 + 2
     for n in names:
         assert open(out1 / n, "rb").read() == open(out2 / n, "rb").read(), n
+
+
+@pytest.mark.parametrize("mode,extra", [("train", []), ("train", ["--dtype", "bf16"]), ("infer", [])])
+def test_bench_under_torchrun_two_ranks(mode, extra):
+    """bench.py launched as the driver launches it for N > 1 (`python -m torch.distributed.run --nproc-per-node N bench.py
+    --gpus N --steps K --warmup W`), here with two ranks sharing the one GPU over gloo (MSL_BENCH_BACKEND: functional
+    rehearsal; the real run is one rank per GPU over RCCL): the set-up phase, the sampled event pairs, the reducer's hooks
+    between program segments and the stop-event forks all run on both ranks, rank 0 prints ONE JSON line whose value is the
+    whole-job aggregate."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MSL_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           "--mode", mode] + extra
+    if mode == "infer":
+        cmd += ["--map-cases", "2", "--train-steps", "2"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    per_step = (4 if mode == "train" else 2) * 2  # volumes of both ranks per step
+    assert abs(d["value"] - per_step / (d["ms_per_step"] * 1e-3)) <= 0.01 * d["value"]
+    assert d["config"]["global_batch"] == per_step
+    if mode == "train":
+        assert d["config"]["parallelism"] == "dp2" and d["roofline"]["launches_timed"] == 3
