@@ -1219,7 +1219,10 @@ class Engine:
                 finally:
                     if presync:
                         on_bucket_ready.presynced = False
-            self._hook(fire, stage)
+            if getattr(on_bucket_ready, "native", False):
+                on_bucket_ready(stage)  # issues C-ABI calls itself (recorded like any other launch): no Python hook
+            else:
+                self._hook(fire, stage)
         return report
 
     def backward(self, pl, dlocs, dscores, on_bucket_ready=None):

@@ -19,6 +19,31 @@ from .parallel import GradBucketReducer
 from .ssd3d import MultiBoxLoss
 
 
+class _StagedOptimizer:
+    """Single-process counterpart of the data-parallel reducer: a gradient bucket that is complete long before the end of the
+    backward pass (70 % of the parameters after the heads and block 7, 98.5 % after block 3) is folded
+    (Engine._grad_reduce) and stepped by Adam right then, on the heads stream beside the remaining backward kernels; the
+    end of the step only has the last 1.5 % (blocks 2-1 + stem) to fold and step.  Same kernels on sub-ranges of the same
+    flat buffers (Adam is elementwise, every reduction keeps its fixed order): bit-identical parameters.  Engine.backward
+    drives it exactly as it drives GradBucketReducer (``trigger`` / ``ranges`` / ``stages`` / ``comm_stream``)."""
+    native = True         # Engine._reporter calls it directly: the launches below are recorded, no Python hook
+    final_on_main = True  # the last bucket on the chain, everything else on comm_stream
+
+    def __init__(self, reducer, opt, comm_stream):
+        self.trigger, self.ranges = reducer.trigger, reducer.ranges
+        self.stages = set(self.trigger.keys())
+        self.opt, self.comm_stream = opt, comm_stream
+        self.main_stream = None  # raw handle of the chain's stream, set by the trainer before each backward pass
+
+    def __call__(self, stage):
+        arena, opt = self.opt._ensure(), self.opt
+        st = self.main_stream if stage == 0 else self.comm_stream.cuda_stream
+        for k in self.trigger.get(stage, []):
+            lo, hi = self.ranges[k]
+            _lib.call("msl_adam_step", ptr(arena.flat[lo:]), ptr(arena.grad[lo:]), ptr(opt.exp_avg[lo:]), ptr(opt.exp_avg_sq[lo:]),
+                      ptr(opt.hp), ptr(arena.is_bias[lo:]), hi - lo, st, tag=f"adam_bucket{k}")
+
+
 class FusedTrainer:
     def __init__(self, model, lr=None, n_buckets=3, process_group=None):
         self.model = model
@@ -34,6 +59,12 @@ class FusedTrainer:
         # the upload of the optimiser's hyper-parameters waits for the previous step through an event of the launch program
         # (a stop event of the Adam launch) instead of a torch wait_stream, which put a record at the head of the chain
         self.hp_wait_event = True
+        # single process: fold and step each gradient bucket as soon as it is complete (_StagedOptimizer) instead of one
+        # reduction + one Adam launch over everything at the end of the step.  Bit-identical, and measured SLOWER (same-box
+        # A/B: fp32 0.667 -> 0.684 ms, bf16 0.646 -> 0.669): the 14 us it takes off the end of the chain cost less than making
+        # the heads stream wait, twice per backward pass, for everything the other streams hold - off by default
+        self.staged_adam = False
+        self._stager = None
         self._programs = collections.OrderedDict()  # LRU, at most max_programs entries (each pins its input tensors)
         self.max_programs = 16
         self._staging = {}         # (image shape, target capacity) -> persistent input buffers (see _stage)
@@ -88,6 +119,16 @@ class FusedTrainer:
                 after = {k: run_match}
             else:
                 run_match()
+        # single process, three streams: the optimiser steps bucket by bucket during the backward pass (its hyper-parameters
+        # must then be in place before the first bucket: uploaded here, in front of the forward pass)
+        stager = None
+        if self.staged_adam and eng.multi_stream and not red.active and len(red.ranges) > 1:
+            if self._stager is None or self._stager.ranges is not red.ranges:
+                self._stager = _StagedOptimizer(red, self.opt, eng.side_streams(dev)[0])
+            stager = self._stager
+            stager.main_stream = main
+            self.opt._ensure()
+            self.opt.prepare_step(grad_scale=1.0)
         locs, scores = eng.forward(images, training=True, need_grad=True, nan_check=False, after_block=after)
         pl = eng.plan_for(images, True)
         if eng.multi_stream:
@@ -101,16 +142,17 @@ class FusedTrainer:
             lf._run_loss_pack(st, locs, scores, st["upstream_alpha"], pl.nan_flag, [pl.dO[f] for f in pl.feat_ids],
                               [pl.dims[f] for f in pl.feat_ids], [pl.prior_off[f] for f in pl.feat_ids])
             pl.loss_fold = (st["pack_parts"], st["pack_parts"].numel() // 2, st["loss_out"], st["npos"])
-            eng.backward(pl, None, None, on_bucket_ready=red)
+            eng.backward(pl, None, None, on_bucket_ready=stager or red)
         else:
             pl.loss_fold = None
             lf._run_forward(st, locs, scores, gt_boxes, gt_labels, obj_off, total_objects,
                             with_backward_upstream=st["upstream_alpha"], matched=eng.multi_stream, nan_flag=pl.nan_flag)
-            eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=red)
-        scale = red.finish()
-        if red.active:
-            _lib.record_hook(red.finish, tag="hook:finish")
-        self.opt.step(grad_scale=scale, gather_autograd_grads=False)
+            eng.backward(pl, st["dlocs"], st["dscores"], on_bucket_ready=stager or red)
+        if stager is None:
+            scale = red.finish()
+            if red.active:
+                _lib.record_hook(red.finish, tag="hook:finish")
+            self.opt.step(grad_scale=scale, gather_autograd_grads=False)
         if eng.multi_stream and eng.prologue_on_side:
             # "the optimiser has read its hyper-parameter vector": what the NEXT step's upload of that vector waits for.  Part
             # of the launch program (behind the Adam launch it is a stop event: no packet of its own), so that the next step

@@ -569,25 +569,27 @@ def test_engine_schedule_options_agree():
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_launch_placement_options_are_bit_identical(dtype):
     """Where side work is enqueued (target matching after block 0 / 2 / 4 / past the last block), whether the tail blocks'
-    pointwise weight gradients and the head gradient images share a launch: pure scheduling - three optimisation steps end at
-    bit-identical parameters and losses."""
+    pointwise weight gradients and the head gradient images share a launch, whether Adam steps bucket by bucket during the
+    backward pass or once at its end: pure scheduling - three optimisation steps end at bit-identical parameters and losses."""
     from mslesions3d_amd.trainer import FusedTrainer
     size, n = (64, 64, 64), 2
     x = detinit.make_volume_batch(5, n, 1, size).to(DEV)
     boxes, labels = detinit.make_gt(8, n, size)
     boxes, labels = [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels]
     ref = None
-    for match_after, batch_pw, batch_gp in [(4, True, True), (0, True, True), (2, False, True), (99, True, False), (4, False, False)]:
+    for match_after, batch_pw, batch_gp, staged in [(4, True, True, True), (0, True, True, False), (2, False, True, True),
+                                                    (99, True, False, False), (4, False, False, False), (4, False, True, True)]:
         m = hip_model(1, size, lr=1e-3, batch_size=n).train()
         m.compute_dtype = dtype
         m._engine.batch_tail_pw, m._engine.batch_head_gpack = batch_pw, batch_gp
         tr = FusedTrainer(m)
         tr.match_after = match_after
+        tr.staged_adam = staged  # the optimiser steps bucket by bucket during the backward pass / once at the end
         losses = [tr.step(x, boxes, labels)["loss"] for _ in range(3)]
         p = torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu()
         if ref is None:
             ref = (losses, p)
-        what = f"match_after={match_after} batch_tail_pw={batch_pw} batch_head_gpack={batch_gp}"
+        what = f"match_after={match_after} batch_tail_pw={batch_pw} batch_head_gpack={batch_gp} staged_adam={staged}"
         assert losses == ref[0], what
         assert torch.equal(p, ref[1]), what
 
