@@ -278,6 +278,7 @@ class Engine:
         # tried, and no second rounding of the head operands) or on the bf16 MFMA kernel from a channels-last bf16 copy
         # ("bf16", inference only)
         self.bf16_heads = "f32"
+        self.bf16_materialize_beside = True  # bf16 pass: a scale's fp32 feature copy on the heads stream with its head convolution
         # 0: every block's weight gradients on the wgrad stream; 1: odd blocks on the heads stream (idle once the head
         # gradients are done); 2: three ways, the third on a stream of its own
         self.split_wgrad = 1
@@ -806,12 +807,19 @@ class Engine:
             if training and i in pl.feat_ids:  # the materialisation below reads the vectors
                 self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
             if i in pl.feat_ids and pl.f32_heads:
+                # the fp32 zero-haloed copy only feeds this scale's head convolution: it goes to the heads stream with it
+                # (as in the fp32 pass; 6-8 us per scale off the chain) unless the caller wants the feature map back
+                beside = ms and i != len(specs) - 1
+                on_side = beside and not want_features and self.bf16_materialize_beside
+                if on_side:
+                    self._fork(pl, f"fwd_feat{i}", st, stH)
                 self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16_pad32", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
-                        ptr(pl.bn_y[i][1]), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, st)
+                        ptr(pl.bn_y[i][1]), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, stH if on_side else st)
                 if want_features:
                     out_feats[i] = pl.fpad[i][:, :, 1:-1, 1:-1, 1:-1].clone()
-                if ms and i != len(specs) - 1:  # beside the next blocks, on the heads stream
-                    self._fork(pl, f"fwd_feat{i}", st, stH)
+                if beside:  # beside the next blocks, on the heads stream
+                    if not on_side:
+                        self._fork(pl, f"fwd_feat{i}", st, stH)
                     self._head_forward(pl, i, stH)
                 else:
                     if ev_pack is not None:  # the packed weights come from the heads stream
