@@ -273,6 +273,10 @@ int msl_bn_relu_materialize_bf16(const void* y, const float* scale, const float*
 /* ... fp32 zero-haloed NCDHW copy (N,C,D+2,H+2,W+2) instead: the bf16 TRAINING step runs its heads on the fp32 kernels */
 int msl_bn_relu_materialize_bf16_pad32(const void* y, const float* scale, const float* shift, float* pad, int N, int C, int D,
                                        int H, int W, void* stream);
+/* the same in training mode with the affine folded from the producer's statistics partials ([2][C][in_np]) */
+int msl_bn_relu_materialize_bf16_pad32_fold(const void* y, const double* in_partials, int in_np, double in_count,
+                                            const float* gamma, const float* beta, float eps, float* pad, int N, int C, int D,
+                                            int H, int W, void* stream);
 size_t msl_head_packed_weight_bf16_elems(int C);
 int msl_head_pack_weights_bf16(const float* loc_w, const float* cl_w, void* Wp, int C, int ncls, void* stream);
 /* both head convolutions of a scale on v_mfma_f32_16x16x32_bf16, fp32 rows out */

@@ -97,6 +97,7 @@ _SIGNATURES = {
     "msl_pwconv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "msl_bn_relu_materialize_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msl_bn_relu_materialize_bf16_pad32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "msl_bn_relu_materialize_bf16_pad32_fold": (_I, [_P, _P, _I, _D, _P, _P, _F, _P, _I, _I, _I, _I, _I, _P]),
     "msl_head_packed_weight_bf16_elems": (_Z, [_I]),
     "msl_head_pack_weights_bf16": (_I, [_P, _P, _P, _I, _I, _P]),
     "msl_head_conv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -424,14 +424,26 @@ __global__ __launch_bounds__(256) void materialize_bf16_kernel(const u16* __rest
 // The training step runs its head convolutions on the fp32 kernels (heads.hip: LDS-staged, faster at these sizes than the
 // bf16 head kernel, and the head operands then carry no second rounding): relu(bn(y)) -> fp32 zero-haloed NCDHW copy
 // (N, C, D+2, H+2, W+2), halo zeroed once at allocation.
+// `fold`: the BatchNorm affine of the workgroup's channel rebuilt from the producer's statistics partials (no finalize launch
+// in front; the batched finalize at the end of the pass writes the vectors the backward pass needs)
 __global__ __launch_bounds__(256) void materialize_bf16_pad32_kernel(const u16* __restrict__ y, const float* __restrict__ scale,
                                                                      const float* __restrict__ shift, float* __restrict__ pad,
-                                                                     int C, int D, int H, int W) {
+                                                                     int C, int D, int H, int W, msl::BnFold fold) {
+  __shared__ float s_aff[2];
   const int S = D * H * W;
   const int p = blockIdx.x * 256 + threadIdx.x, c = blockIdx.y, n = blockIdx.z;
+  float sc, sh;
+  if (fold.partials) {
+    msl::bn_fold_block(fold, c, 1, &s_aff[0], &s_aff[1]);  // (all threads: ends with a barrier)
+    sc = s_aff[0];
+    sh = s_aff[1];
+  } else {
+    sc = scale[c];
+    sh = shift[c];
+  }
   if (p >= S) return;
   const int w = p % W, hh = (p / W) % H, d = p / (W * H);
-  const float v = msl::act(msl::bf2f(y[((size_t)n * C + c) * S + p]), scale[c], shift[c]);
+  const float v = msl::act(msl::bf2f(y[((size_t)n * C + c) * S + p]), sc, sh);
   pad[(((size_t)(n * C + c) * (D + 2) + d + 1) * (H + 2) + hh + 1) * (W + 2) + w + 1] = v;
 }
 
@@ -909,7 +921,20 @@ int msl_bn_relu_materialize_bf16_pad32(const void* y, const float* scale, const 
   if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || !scale || !shift || !pad) return MSL_ERR_ARG;
   dim3 grid(msl::cdiv(D * H * W, 256), C, N);
   MSL_LAUNCH(materialize_bf16_pad32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, scale, shift, pad, C,
-                     D, H, W);
+                     D, H, W, pb_nofold);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
+// the same with the affine folded from the producer's statistics partials [2][C][in_np] (training mode)
+int msl_bn_relu_materialize_bf16_pad32_fold(const void* y, const double* in_partials, int in_np, double in_count,
+                                            const float* gamma, const float* beta, float eps, float* pad, int N, int C, int D,
+                                            int H, int W, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || !in_partials || in_np <= 0 || !pad) return MSL_ERR_ARG;
+  const msl::BnFold fold{in_partials, in_np, C, in_count, gamma, beta, eps};
+  dim3 grid(msl::cdiv(D * H * W, 256), C, N);
+  MSL_LAUNCH(materialize_bf16_pad32_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)y, (const float*)nullptr,
+             (const float*)nullptr, pad, C, D, H, W, fold);
   MSL_LAUNCH_CHECK();
   return MSL_OK;
 }

@@ -279,6 +279,7 @@ class Engine:
         # ("bf16", inference only)
         self.bf16_heads = "f32"
         self.bf16_materialize_beside = True  # bf16 pass: a scale's fp32 feature copy on the heads stream with its head convolution
+        self.fold_bf16_feats = True  # bf16 pass: the feature maps' BatchNorms folded into the copy / the next depthwise layer too
         # 0: every block's weight gradients on the wgrad stream; 1: odd blocks on the heads stream (idle once the head
         # gradients are done); 2: three ways, the third on a stream of its own
         self.split_wgrad = 1
@@ -754,6 +755,7 @@ class Engine:
         part = (lambda t: ptr(t)) if training else (lambda t: None)
         L = _lib.load()
         later = []  # BatchNorms folded into their consumer: running statistics + backward vectors in ONE launch at the end
+        folded_feats = set()  # feature maps among them
         ev_bn_done = None
         D, H, W = pl.in_dims
         stem_dw = self._stem_dw_eval(specs, training, N, D, H, W)
@@ -775,14 +777,20 @@ class Engine:
             cnt_prev = N * pd * ph * pw
             # the consumer rebuilds (scale, shift) from the producer's partials when they are few (<= fold_np_max: every wave /
             # workgroup repeats the sum) - no finalize launch between the two; feature maps need the vectors anyway
-            fold_y = (training and self.fold_bf16 and pl.np_y[i - 1] <= max(64, self.fold_np_max) and (i - 1) not in pl.feat_ids
+            # (a feature map whose fp32 copy was made from the partials - folded_feats - is folded here too)
+            fold_y = (training and self.fold_bf16 and pl.np_y[i - 1] <= max(64, self.fold_np_max)
+                      and ((i - 1) not in pl.feat_ids or (i - 1) in folded_feats)
                       and L.msl_dwconv_wave_num_partials(N, sp["cin"], pd, ph, pw, sp["stride"][0]) > 0)
-            if training and not fold_y and (i - 1) not in pl.feat_ids:  # (a feature map's vectors exist already)
+            if training and not fold_y and (i - 1) in folded_feats:  # the copy folded, this consumer cannot: finalize after all
+                self._bn_fwd(bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev, True, st)
+                later.pop([id(e[1]) for e in later].index(id(pl.bn_y[i - 1])))
+            elif training and not fold_y and (i - 1) not in pl.feat_ids:  # (a feature map's vectors exist already)
                 self._bn_fwd(bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev, True, st)
             if i == 1 and stem_dw:
                 pass  # z1 came with the stem
             elif fold_y:
-                later.append((bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev))
+                if (i - 1) not in folded_feats:
+                    later.append((bn_prev, pl.bn_y[i - 1], pl.part_y[i - 1], pl.np_y[i - 1], cnt_prev))
                 self._k(f"dw_fwd{i}", "msl_dwconv_fwd_wave_bf16_fold", ptr(pl.y[i - 1]), ptr(pl.part_y[i - 1]), pl.np_y[i - 1],
                         float(cnt_prev), ptr(bn_prev.weight), ptr(bn_prev.bias), bn_prev.eps, ptr(blk.conv1.weight), ptr(pl.z[i]),
                         ptr(pl.part_z[i]), N, sp["cin"], pd, ph, pw, sp["stride"][0], st)
@@ -804,7 +812,14 @@ class Engine:
                 after_block[i](None)
             if training and later and ms and self.finalize_on_side == "all" and i == len(specs) - 1:
                 ev_bn_done = self._finalize_all_beside(pl, later, st)  # as in the fp32 pass (bf16: measured +0.4 %, so opt-in)
-            if training and i in pl.feat_ids:  # the materialisation below reads the vectors
+            # a feature map's BatchNorm: folded into the fp32 copy (and into the next depthwise layer) from the partials when
+            # they are few - no finalize launch on the chain; else finalised here (the copy below reads the vectors)
+            fold_feat = (training and i in pl.feat_ids and pl.f32_heads and self.fold_bf16 and self.fold_bf16_feats
+                         and pl.np_y[i] <= max(64, self.fold_np_max) and not want_features)
+            if fold_feat:
+                folded_feats.add(i)
+                later.append((blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S))
+            elif training and i in pl.feat_ids:
                 self._bn_fwd(blk.bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], N * S, True, st)
             if i in pl.feat_ids and pl.f32_heads:
                 # the fp32 zero-haloed copy only feeds this scale's head convolution: it goes to the heads stream with it
@@ -813,8 +828,13 @@ class Engine:
                 on_side = beside and not want_features and self.bf16_materialize_beside
                 if on_side:
                     self._fork(pl, f"fwd_feat{i}", st, stH)
-                self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16_pad32", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
-                        ptr(pl.bn_y[i][1]), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, stH if on_side else st)
+                if fold_feat:
+                    self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16_pad32_fold", ptr(pl.y[i]), ptr(pl.part_y[i]),
+                            pl.np_y[i], float(N * S), ptr(blk.bn2.weight), ptr(blk.bn2.bias), blk.bn2.eps, ptr(pl.fpad[i]), N,
+                            sp["cout"], D, H, W, stH if on_side else st)
+                else:
+                    self._k(f"materialize{i}", "msl_bn_relu_materialize_bf16_pad32", ptr(pl.y[i]), ptr(pl.bn_y[i][0]),
+                            ptr(pl.bn_y[i][1]), ptr(pl.fpad[i]), N, sp["cout"], D, H, W, stH if on_side else st)
                 if want_features:
                     out_feats[i] = pl.fpad[i][:, :, 1:-1, 1:-1, 1:-1].clone()
                 if beside:  # beside the next blocks, on the heads stream
