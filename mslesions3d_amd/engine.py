@@ -279,6 +279,7 @@ class Engine:
         # ("bf16", inference only)
         self.bf16_heads = "f32"
         self.bf16_materialize_beside = True  # bf16 pass: a scale's fp32 feature copy on the heads stream with its head convolution
+        self.eval_multi_stream_bf16 = True  # bf16 inference: heads of the earlier scales on the heads stream, as in fp32
         self.fold_bf16_feats = True  # bf16 pass: the feature maps' BatchNorms folded into the copy / the next depthwise layer too
         # 0: every block's weight gradients on the wgrad stream; 1: odd blocks on the heads stream (idle once the head
         # gradients are done); 2: three ways, the third on a stream of its own
@@ -732,7 +733,10 @@ class Engine:
         pl.generation += 1
         pl.saved_input, pl.trained_mode = x, training
         st = self._stream()
-        ms = self.multi_stream and need_grad  # heads of the earlier scales beside the backbone (training step)
+        # heads of the earlier scales beside the backbone: the training step, and inference too when the heads run on the fp32
+        # kernels (eval_multi_stream_bf16; the bf16 inference pass used to be one stream: 86 us of feature copies and head
+        # convolutions on the chain at 192^3 x 2)
+        ms = self.multi_stream and (need_grad or (self.eval_multi_stream_bf16 and pl.f32_heads))
         stH = self.side_streams(x.device)[0].cuda_stream if ms else st
         N = pl.N
         ncls = m.n_classes
