@@ -245,6 +245,10 @@ int msl_dwconv_wave_num_partials(int N, int C, int D, int H, int W, int stride);
  * are not powers of two, e.g. the 96^2 ... 12^2 planes of a 192^3 volume): fp32 inside msl_dwconv_fwd, bf16 inside
  * msl_dwconv_fwd_wave_bf16 / msl_dwconv_fwd_bf16 when partials == NULL.  mobilenet.py:37-39 */
 int msl_dwconv_fwd_eval_rows_ok(int N, int C, int D, int H, int W, int stride);
+/* bf16 storage, statistics-free forward of a map of at most 512 voxels (one wave per (image, channel), volume in LDS);
+ * msl_dwconv_fwd_bf16 takes this route by itself in eval mode */
+int msl_dwconv_fwd_small_eval_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y, int N,
+                                   int C, int D, int H, int W, int stride, void* stream);
 int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                              double* partials, int N, int C, int D, int H, int W, int stride, int flip, int accumulate,
                              void* stream);

@@ -92,6 +92,7 @@ _SIGNATURES = {
     "msl_dwconv_s2_bwd_bnreduce_bww_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "msl_stem_conv_bwd_weight_fused_bf16": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_bwd_weight_wave_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "msl_dwconv_fwd_small_eval_bf16": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_dwconv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "msl_pwconv_fwd_bf16_num_partials": (_I, [_I, _I]),
     "msl_pwconv_fwd_bf16": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

@@ -15,6 +15,8 @@ extern "C" int msl_dwconv_fwd_eval_rows_ok(int N, int C, int D, int H, int W, in
 extern "C" int msl_dwconv_fwd_wave_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
                                         double* partials, int N, int C, int D, int H, int W, int stride, int flip,
                                         int accumulate, void* stream);
+extern "C" int msl_dwconv_fwd_small_eval_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y,
+                                              int N, int C, int D, int H, int W, int stride, void* stream);
 extern "C" int msl_dwconv_bwd_data_s2_patch_bf16(const void* dy, const float* w, void* g_in, const void* y_prev, const float* bn_vec,
                                                  double* partials, int N, int C, int D, int H, int W, int accumulate,
                                                  void* stream);
@@ -847,6 +849,8 @@ int msl_dwconv_fwd_bf16(const void* x, const float* in_scale, const float* in_sh
   if (dw_bf16_use_wave() && (msl_dwconv_wave_num_partials(N, C, D, H, W, stride) > 0 ||
                              (!partials && msl_dwconv_fwd_eval_rows_ok(N, C, D, H, W, stride) == 1)))
     return msl_dwconv_fwd_wave_bf16(x, in_scale, in_shift, w, y, partials, N, C, D, H, W, stride, 0, 0, stream);
+  if (!partials && D * H * W <= 512 && (D + 2) * (H + 2) * (W + 2) <= 1024)  // eval mode, a map no wave / rows kernel takes
+    return msl_dwconv_fwd_small_eval_bf16(x, in_scale, in_shift, w, y, N, C, D, H, W, stride, stream);
   const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
   const int tiles_d = msl::cdiv(OD, DW_TD), tiles_h = msl::cdiv(OH, DW_TH), tiles_w = msl::cdiv(OW, DW_TW);
   const int NP = N * tiles_d * tiles_h * tiles_w;

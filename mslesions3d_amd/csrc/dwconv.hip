@@ -1373,9 +1373,10 @@ __global__ __launch_bounds__(256) void dw_fwd_naive_kernel(
 // workgroups.  Taps in the naive kernel's order (kd, kh, kw); a padded tap adds w * 0 where the naive kernel skips it:
 // the same value bit for bit (an fmaf with a zero product leaves a non-negative-zero accumulator unchanged).
 constexpr int DW_SMALL_VOX = 512, DW_SMALL_IMG = 1024;
-__global__ __launch_bounds__(256) void dw_small_eval_kernel(const float* __restrict__ x, const float* __restrict__ in_scale,
+template <typename T>
+__global__ __launch_bounds__(256) void dw_small_eval_kernel(const T* __restrict__ x, const float* __restrict__ in_scale,
                                                             const float* __restrict__ in_shift, const float* __restrict__ w,
-                                                            float* __restrict__ y, int NC, int C, int D, int H, int W, int OD,
+                                                            T* __restrict__ y, int NC, int C, int D, int H, int W, int OD,
                                                             int OH, int OW, int stride) {
   __shared__ float img_all[4][DW_SMALL_IMG];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1387,10 +1388,10 @@ __global__ __launch_bounds__(256) void dw_small_eval_kernel(const float* __restr
   const float sc = affine ? in_scale[c] : 1.f, sh = affine ? in_shift[c] : 0.f;
   for (int i = lane; i < vol; i += 64) img[i] = 0.f;
   __builtin_amdgcn_wave_barrier();  // (a wave's LDS operations execute in order; this only pins the compiler's order)
-  const float* xc = x + (size_t)nc * S;
+  const T* xc = x + (size_t)nc * S;
   for (int i = lane; i < S; i += 64) {
     const int iw = i % W, ih = (i / W) % H, id = i / (W * H);
-    float v = xc[i];
+    float v = msl::ld1(xc + i);
     if (affine) v = msl::act(v, sc, sh);
     img[((id + 1) * Hp + ih + 1) * Wp + iw + 1] = v;
   }
@@ -1408,7 +1409,8 @@ __global__ __launch_bounds__(256) void dw_small_eval_kernel(const float* __restr
       for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
         for (int kw = 0; kw < 3; ++kw) acc = fmaf(wk[kd * 9 + kh * 3 + kw], tp[(kd * Hp + kh) * Wp + kw], acc);
-    y[(size_t)nc * OS + o] = acc;
+    if constexpr (sizeof(T) == 2) y[(size_t)nc * OS + o] = msl::f2bf(acc);
+    else y[(size_t)nc * OS + o] = acc;
   }
 }
 
@@ -1877,6 +1879,18 @@ int msl_dwconv_s1_bwd_data_resident(const float* dy, const float* w, float* g_in
   return MSL_OK;
 }
 
+// bf16 storage, statistics-free forward of a map of at most 512 voxels (dw_small_eval_kernel); MSL_ERR_UNSUPPORTED if larger
+int msl_dwconv_fwd_small_eval_bf16(const void* x, const float* in_scale, const float* in_shift, const float* w, void* y, int N,
+                                   int C, int D, int H, int W, int stride, void* stream) {
+  if (N <= 0 || C <= 0 || D <= 0 || H <= 0 || W <= 0 || (stride != 1 && stride != 2)) return MSL_ERR_ARG;
+  if (D * H * W > DW_SMALL_VOX || (D + 2) * (H + 2) * (W + 2) > DW_SMALL_IMG) return MSL_ERR_UNSUPPORTED;
+  const int OD = (D - 1) / stride + 1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+  MSL_LAUNCH(dw_small_eval_kernel<dwu16>, dim3(msl::cdiv(N * C, 4)), dim3(256), 0, (hipStream_t)stream, (const dwu16*)x,
+             in_scale, in_shift, w, (dwu16*)y, N * C, C, D, H, W, OD, OH, OW, stride);
+  MSL_LAUNCH_CHECK();
+  return MSL_OK;
+}
+
 static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* in_shift, const msl::BnFold& fold,
                            const float* w, float* y, double* partials, int N, int C, int D, int H, int W, int stride,
                            int force_naive, void* stream) {
@@ -1898,8 +1912,8 @@ static int dwconv_fwd_impl(const float* x, const float* in_scale, const float* i
     }
   }
   if (!force_naive && !partials && !fold.partials && D * H * W <= DW_SMALL_VOX && (D + 2) * (H + 2) * (W + 2) <= DW_SMALL_IMG) {
-    MSL_LAUNCH(dw_small_eval_kernel, dim3(msl::cdiv(N * C, 4)), dim3(256), 0, st, x, in_scale, in_shift, w, y, N * C, C, D, H,
-               W, OD, OH, OW, stride);
+    MSL_LAUNCH(dw_small_eval_kernel<float>, dim3(msl::cdiv(N * C, 4)), dim3(256), 0, st, x, in_scale, in_shift, w, y, N * C, C,
+               D, H, W, OD, OH, OW, stride);
     MSL_LAUNCH_CHECK();
     return MSL_OK;
   }

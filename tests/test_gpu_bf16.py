@@ -85,6 +85,25 @@ def test_dw_fwd_eval_rows_bf16(N, C, dims, stride):
     close(y.float(), ref, 2 * BF_EPS, 1e-5, "dw fwd bf16 (eval rows)")
 
 
+@pytest.mark.parametrize("N,C,dims,stride", [(2, 512, (6, 6, 6), 1), (2, 7, (6, 6, 6), 2), (1, 5, (3, 5, 7), 1), (1, 2, (1, 1, 1), 1)])
+def test_dw_fwd_eval_small_maps_bf16(N, C, dims, stride):
+    """Statistics-free forward of maps of at most 512 voxels on bf16 storage (the 6^3 map of a 192^3 volume): the wave-per-channel
+    LDS kernel, through msl_dwconv_fwd_bf16 and directly, against fp32 conv3d on the same bf16-rounded input."""
+    x = bfr(rnd(N, C, *dims, seed=4))
+    w = rnd(C, 1, 3, 3, 3, seed=5, scale=0.4)
+    sc, sh = rnd(C, seed=6).abs() + 0.5, rnd(C, seed=7, scale=0.3)
+    a = torch.relu(x * sc.view(1, -1, 1, 1, 1) + sh.view(1, -1, 1, 1, 1))
+    ref = F.conv3d(a, w, stride=stride, padding=1, groups=C)
+    y = torch.full(ref.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    y2 = torch.full(ref.shape, float("nan"), dtype=torch.bfloat16, device=DEV)
+    _lib.call("msl_dwconv_fwd_bf16", ptr(K(x.to(torch.bfloat16))), ptr(K(sc)), ptr(K(sh)), ptr(K(w)), ptr(y), None, N, C, *dims, stride, st())
+    _lib.call("msl_dwconv_fwd_small_eval_bf16", ptr(K(x.to(torch.bfloat16))), ptr(K(sc)), ptr(K(sh)), ptr(K(w)), ptr(y2), N, C, *dims, stride, st())
+    close(y.float(), ref, 2 * BF_EPS, 1e-5, "dw fwd bf16 (small map)")
+    assert torch.equal(y, y2)
+    with pytest.raises(_lib.HipKernelError):
+        _lib.call("msl_dwconv_fwd_small_eval_bf16", ptr(y), None, None, ptr(K(w)), ptr(y2), 1, 1, 16, 16, 16, 1, st())
+
+
 @pytest.mark.parametrize("N,Cin,Cout,S", [(2, 32, 64, 1000), (1, 64, 128, 64), (2, 128, 128, 130), (1, 512, 512, 8),
                                           (1, 256, 512, 27), (2, 128, 256, 1728), (1, 32, 96, 200),
                                           # whole 64-position tiles: the pipelined transposed-read kernel (K chunks of 32 / 64 /
