@@ -595,30 +595,39 @@ __global__ __launch_bounds__(HEAD_FWD_NT) void head_fwd_lds_kernel(const float* 
       head_ld_f1(sv, abase + (size_t)(ck + 1) * CH * volp, goff);
       head_ld_f4<NA, NT>(av, wbase + (size_t)(ck + 1) * AF4, tid, AF4);
     }
+    // The operand reads of the wave's SECOND channel group are issued between the MFMAs of its first one (order pinned):
+    // reads and matrix work of one wave overlap - the two waves of a SIMD run in lock-step between the chunk barriers, so
+    // nothing else overlaps them
+    static_assert(NCG / 2 == 2, "two channel groups per wave and chunk");
+    {
+      const int cga = khalf * 2, cgb = cga + 1;
+      const float* spa = slab + (cga * 4 + q) * G::CS + ob;
+      const float* spb = slab + (cgb * 4 + q) * G::CS + ob;
+      const float* fpa = afr + (size_t)cga * 27 * MT * 64 + lane;
+      const float* fpb = afr + (size_t)cgb * 27 * MT * 64 + lane;
+      float bqa[27], aqa[27 * MT], bqb[27], aqb[27 * MT];
 #pragma unroll
-    for (int cg2 = 0; cg2 < NCG / 2; ++cg2) {
-      const int cgl = khalf * (NCG / 2) + cg2;
-      const float* sp = slab + (cgl * 4 + q) * G::CS + ob;
-      const float* fp = afr + (size_t)cgl * 27 * MT * 64 + lane;
-      // all operand reads of the channel group leave before its first MFMA (left to itself the compiler reads two operands,
-      // waits, issues two MFMAs).  Measured neutral with two waves per SIMD (27.3 -> 27.8 us at 16^3): the loop is bound by
-      // LDS bytes - two 256-byte operand reads per 32-cycle MFMA are half of the CU's LDS bandwidth - not by their latency
-      float bq[27], aq[27 * MT];
+      for (int t = 0; t < 27; ++t) bqa[t] = spa[((t / 9) * G::PH + (t / 3) % 3) * G::PW + t % 3];
 #pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) bq[kd * 9 + kh * 3 + kw] = sp[(kd * G::PH + kh) * G::PW + kw];
-#pragma unroll
-      for (int t = 0; t < 27 * MT; ++t) aq[t] = fp[t * 64];
-      __builtin_amdgcn_sched_barrier(0);
+      for (int t = 0; t < 27 * MT; ++t) aqa[t] = fpa[t * 64];
 #pragma unroll
       for (int tap = 0; tap < 27; ++tap) {
 #pragma unroll
         for (int m = 0; m < MT; ++m) {
-          if (tap & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap * MT + m], bq[tap], acc2[m], 0, 0, 0);
-          else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap * MT + m], bq[tap], acc[m], 0, 0, 0);
+          if (tap & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aqa[tap * MT + m], bqa[tap], acc2[m], 0, 0, 0);
+          else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aqa[tap * MT + m], bqa[tap], acc[m], 0, 0, 0);
+        }
+        bqb[tap] = spb[((tap / 9) * G::PH + (tap / 3) % 3) * G::PW + tap % 3];
+#pragma unroll
+        for (int m = 0; m < MT; ++m) aqb[tap * MT + m] = fpb[(tap * MT + m) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+#pragma unroll
+        for (int m = 0; m < MT; ++m) {
+          if (tap & 1) acc2[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aqb[tap * MT + m], bqb[tap], acc2[m], 0, 0, 0);
+          else acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(aqb[tap * MT + m], bqb[tap], acc[m], 0, 0, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -693,26 +702,34 @@ __global__ __launch_bounds__(256) void head_bwd_data_lds_kernel(const float* __r
     __syncthreads();  // also publishes the dO slab on the first pass
     if (ct + 1 < ct_hi) head_ld_f4(av, wb4 + (size_t)(ct + 1) * AF4, tid, AF4);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f}, acc2 = {0.f, 0.f, 0.f, 0.f};  // two chains: see head_fwd_lds_kernel
+    // software pipeline over the output-channel groups: the operand reads of group g + 1 ride between the MFMAs of group g
+    // (order pinned; same accumulation order as the plain loop - see head_fwd_lds_kernel)
+    static_assert(COG % 2 == 0, "groups are walked in pairs");
+    auto rd = [&](int cog, int tap, float& b_, float& a_) {
+      const int kd = tap / 9, kh = (tap / 3) % 3, kw = tap % 3;
+      b_ = slab[(cog * 4 + q) * G::CS + ob + ((2 - kd) * G::PH + (2 - kh)) * G::PW + (2 - kw)];
+      a_ = afr[(size_t)cog * 27 * 64 + lane + tap * 64];
+    };
+    float bqa[27], aqa[27], bqb[27], aqb[27];
+#pragma unroll
+    for (int t = 0; t < 27; ++t) rd(0, t, bqa[t], aqa[t]);
 #pragma unroll 1
-    for (int cog = 0; cog < COG; ++cog) {
-      const float* sp = slab + (cog * 4 + q) * G::CS + ob;
-      const float* fp = afr + (size_t)cog * 27 * 64 + lane;
-      float bq[27], aq[27];  // all operand reads of the group first, then its MFMAs (see head_fwd_lds_kernel)
-#pragma unroll
-      for (int kd = 0; kd < 3; ++kd)
-#pragma unroll
-        for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-          for (int kw = 0; kw < 3; ++kw) bq[kd * 9 + kh * 3 + kw] = sp[((2 - kd) * G::PH + (2 - kh)) * G::PW + (2 - kw)];
-#pragma unroll
-      for (int t = 0; t < 27; ++t) aq[t] = fp[t * 64];
-      __builtin_amdgcn_sched_barrier(0);
+    for (int cog = 0; cog < COG; cog += 2) {
 #pragma unroll
       for (int tap = 0; tap < 27; ++tap) {
-        if (tap & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap], bq[tap], acc2, 0, 0, 0);
-        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aq[tap], bq[tap], acc, 0, 0, 0);
+        if (tap & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aqa[tap], bqa[tap], acc2, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aqa[tap], bqa[tap], acc, 0, 0, 0);
+        rd(cog + 1, tap, bqb[tap], aqb[tap]);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      const bool more = cog + 2 < COG;  // uniform
+#pragma unroll
+      for (int tap = 0; tap < 27; ++tap) {
+        if (tap & 1) acc2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aqb[tap], bqb[tap], acc2, 0, 0, 0);
+        else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(aqb[tap], bqb[tap], acc, 0, 0, 0);
+        if (more) rd(cog + 2, tap, bqa[tap], aqa[tap]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
     acc += acc2;
 #pragma unroll

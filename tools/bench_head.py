@@ -43,7 +43,7 @@ def timeit(fn, reps=50):
 gf = 2.0 * N * S * C * 27 * 16 / 1e9
 t = timeit(lambda: _lib.call("msl_head_conv_fwd", ptr(pad), ptr(Wf), ptr(lb), ptr(cb), ptr(locs), ptr(scores), ptr(ws), N, C, D, D, D, P, 0, ncls, st))
 print(f"head fwd      {D}^3 x{N} C={C}: {t:6.1f} us  {gf / t * 1e3:6.1f} TFLOP/s")
-if os.environ.get("HEAD_FWD_ONLY"):
+if os.environ.get("HEAD_FWD_ONLY") == "1":
     sys.exit(0)
 t = timeit(lambda: _lib.call("msl_head_conv_bwd_data", ptr(dO), ptr(Wb), ptr(ga), N, C, D, D, D, ncls, st))
 print(f"head bwd-data {D}^3 x{N} C={C}: {t:6.1f} us  {gf / t * 1e3:6.1f} TFLOP/s")
