@@ -486,6 +486,8 @@ def main():
                                       "bf16 activations + activation gradients / fp32 weights, accumulators and Adam, "
                                       "SSD3D+MobileNet3D full train step (BASELINE configs[2])"),
                        "global_batch": world * args.batch, "parallelism": f"dp{world}", "priors": pl.P,
+                       "setup": "before the W warm-up steps: the launch program of each of the 4 resident batches recorded (one "
+                                "step through the Python executor) and both replay variants compiled (untimed)",
                        "last_loss": {"conf": conf, "loc": loc, "n_positives": npos}},
             "roofline": {"bound": "hbm", "kernel": dw1_kernel + " (depthwise 3x3x3 s2 forward, block 1)",
                          "achieved": None if achieved is None else round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
