@@ -279,6 +279,7 @@ class Engine:
         # ("bf16", inference only)
         self.bf16_heads = "f32"
         self.bf16_materialize_beside = True  # bf16 pass: a scale's fp32 feature copy on the heads stream with its head convolution
+        self.early_loss_fork = True  # fp32 backward: the heads stream is released by the loss launch itself (its stop event)
         self.eval_multi_stream_bf16 = True  # bf16 inference: heads of the earlier scales on the heads stream, as in fp32
         self.fold_bf16_feats = True  # bf16 pass: the feature maps' BatchNorms folded into the copy / the next depthwise layer too
         # 0: every block's weight gradients on the wgrad stream; 1: odd blocks on the heads stream (idle once the head
@@ -1310,6 +1311,11 @@ class Engine:
             tail = tail[:4] if len(tail) >= 2 else []
         tail_args = []
         ev_loss = None
+        if side_feats and self.early_loss_fork:
+            # the earlier scales' gradients (heads stream) need the head-gradient images - written by the launch in front
+            # of this point (the loss kernel, or the batched pack), whose stop event this record becomes: no packet on the
+            # chain, and the heads stream starts one launch earlier than behind the chain's own head bwd-data
+            self._fork(pl, "bwd_loss_ready", st, stH)
         for f in pl.feat_ids:  # the chain's own scale first: its data gradient starts the backward chain
             if f not in side_feats:
                 if ms:
@@ -1319,8 +1325,7 @@ class Engine:
                                                        self._head_backward(pl, f, dlocs, dscores, stW, data=False)))
                 else:
                     self._head_backward(pl, f, dlocs, dscores, st, packed=packed)
-        if side_feats:
-            # the earlier scales' gradients (heads stream) need the head-gradient images
+        if side_feats and not self.early_loss_fork:
             # (sharing the record behind the chain's own head bwd-data instead - one launch later, one record fewer - was
             # measured 1-2 % SLOWER: the heads stream's gradients are as critical as the chain here)
             self._fork(pl, "bwd_loss_ready", st, stH)
