@@ -279,6 +279,9 @@ class Engine:
         # ("bf16", inference only)
         self.bf16_heads = "f32"
         self.bf16_materialize_beside = True  # bf16 pass: a scale's fp32 feature copy on the heads stream with its head convolution
+        # set by a caller (FusedTrainer) while it records a step whose heads stream it orders itself, every step, behind the
+        # previous step's optimiser: the forward pass then has no "fwd_start" record at the head of the chain
+        self.prologue_presynced = False
         self.early_loss_fork = True  # fp32 backward: the heads stream is released by the loss launch itself (its stop event)
         self.eval_multi_stream_bf16 = True  # bf16 inference: heads of the earlier scales on the heads stream, as in fp32
         self.fold_bf16_feats = True  # bf16 pass: the feature maps' BatchNorms folded into the copy / the next depthwise layer too
@@ -472,7 +475,8 @@ class Engine:
             # convolution) and at its end (loss / NaN checks): on the heads stream they cost the dependency chain nothing
             # (in front of the stem they were a memset + a launch + two dispatch gaps, ~20 us).  The heads stream first waits
             # for everything the chain has done so far (the previous step's optimiser wrote the weights).
-            self._fork(pl, "fwd_start", st, stH)
+            if not self.prologue_presynced:  # (a caller that orders the heads stream itself: FusedTrainer)
+                self._fork(pl, "fwd_start", st, stH)
             _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, stH)
             self._pack_head_weights(pl, stH)
             ev_pack = self._record(pl, "head_pack_done", stH)
@@ -744,7 +748,8 @@ class Engine:
         side_prologue = ms and self.prologue_on_side and pl.f32_heads  # as in the fp32 forward: off the dependency chain
         ev_pack = None
         if side_prologue:
-            self._fork(pl, "fwd_start", st, stH)
+            if not self.prologue_presynced:
+                self._fork(pl, "fwd_start", st, stH)
             _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, stH)
             self._pack_head_weights(pl, stH)
             ev_pack = self._record(pl, "head_pack_done", stH)

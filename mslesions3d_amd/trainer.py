@@ -59,6 +59,8 @@ class FusedTrainer:
         # the upload of the optimiser's hyper-parameters waits for the previous step through an event of the launch program
         # (a stop event of the Adam launch) instead of a torch wait_stream, which put a record at the head of the chain
         self.hp_wait_event = True
+        self._step_done = None  # event recorded behind every step's optimiser launch (any plan)
+        self.presync_prologue = True  # no "fwd_start" record in the step's program: the trainer orders the heads stream itself
         # single process: fold and step each gradient bucket as soon as it is complete (_StagedOptimizer) instead of one
         # reduction + one Adam launch over everything at the end of the step.  Bit-identical, and measured SLOWER (same-box
         # A/B: fp32 0.667 -> 0.684 ms, bf16 0.646 -> 0.669): the 14 us it takes off the end of the chain cost less than making
@@ -129,7 +131,17 @@ class FusedTrainer:
             stager.main_stream = main
             self.opt._ensure()
             self.opt.prepare_step(grad_scale=1.0)
-        locs, scores = eng.forward(images, training=True, need_grad=True, nan_check=False, after_block=after)
+        # The heads stream's prologue (NaN-flag reset, head-weight packing) has to follow the previous step's optimiser.  The
+        # trainer orders it itself - here through torch, in every replayed step through the "step_done" event of the previous
+        # step's program (see step_packed) - so the recorded forward pass carries no event record at the head of the chain
+        presync = self.presync_prologue and eng.multi_stream and eng.prologue_on_side
+        if presync:
+            eng.side_streams(dev)[0].wait_stream(torch.cuda.current_stream(dev))
+        eng.prologue_presynced = presync
+        try:
+            locs, scores = eng.forward(images, training=True, need_grad=True, nan_check=False, after_block=after)
+        finally:
+            eng.prologue_presynced = False
         pl = eng.plan_for(images, True)
         if eng.multi_stream:
             eng._fork(pl, "match_done", sM, main)
@@ -157,7 +169,11 @@ class FusedTrainer:
             # "the optimiser has read its hyper-parameter vector": what the NEXT step's upload of that vector waits for.  Part
             # of the launch program (behind the Adam launch it is a stop event: no packet of its own), so that the next step
             # need not put a record at the head of the chain
-            eng._record(pl, "step_done", main)
+            # ONE event per trainer, whatever plan (input shape) a step ran on: the wait of the next step must mean "the most
+            # recent step", also when steps of different shapes alternate
+            if self._step_done is None:
+                self._step_done = _lib.new_event(device_only=True)
+            _lib.call("msl_event_record", self._step_done, main, tag="event")
         return pl, st
 
     def _stage(self, images, gt_boxes, gt_labels, obj_off, total_objects):
@@ -259,11 +275,13 @@ class FusedTrainer:
                     # step: copy it on the heads stream, which the chain joins before the optimiser anyway, instead of in
                     # front of the stem (the stream first waits for the previous step's optimiser, which still reads it)
                     sH = eng.side_streams(dev)[0]
-                    done = pl.events.get("step_done") if self.hp_wait_event else None
+                    done = self._step_done if self.hp_wait_event else None
                     if done is not None:  # recorded by the previous step's program, right behind its optimiser launch
                         eng._wait(sH.cuda_stream, done)
                     else:
                         sH.wait_stream(self._stream)
+                    if not unfenced:  # a fenced step: whatever the caller's stream holds (the chain waits for it above)
+                        sH.wait_stream(caller)
                     with torch.cuda.stream(sH):
                         self.opt.prepare_step(grad_scale=1.0 / red.world)
                 else:

@@ -652,6 +652,33 @@ def test_cheap_forks_are_bit_identical_to_plain_event_records(size, n, steps):
                 assert torch.equal(u[i], v[i])
 
 
+def test_steps_of_alternating_shapes_order_their_prologues_behind_the_latest_step():
+    """FusedTrainer orders the heads stream's prologue (head-weight packing, NaN-flag reset) and the upload of the optimiser's
+    hyper-parameters behind "the previous step" through ONE trainer-level event, whatever plan (input shape) that step ran
+    on: replayed steps that alternate between two shapes (each with its own launch program, a learning-rate schedule that
+    changes every step) end at the parameters and losses of the same steps ordered through torch's stream waits."""
+    from mslesions3d_amd.trainer import FusedTrainer
+    shapes = [((64, 64, 64), 2), ((64, 64, 64), 1)]  # (the plan is per batch shape: two plans, two launch programs)
+    data = []
+    for k, (size, n) in enumerate(shapes):
+        x = detinit.make_volume_batch(5 + k, n, 1, size).to(DEV)
+        boxes, labels = detinit.make_gt(8 + k, n, size)
+        data.append((x, [b.to(DEV) for b in boxes], [t.to(DEV) for t in labels]))
+    out = []
+    for cheap in (False, True):
+        m = hip_model(1, shapes[0][0], lr=1e-3, batch_size=2).train()
+        assert m.scheduler != "none"  # the learning rate changes every step: a hyper-parameter upload that raced would show
+        tr = FusedTrainer(m)
+        tr.presync_prologue = tr.hp_wait_event = cheap
+        losses = []
+        for s in range(24):
+            x, b, l = data[s % 2] if s % 5 else data[0]  # (irregular alternation)
+            losses.append(tr.step(x, b, l)["loss"])
+        out.append((losses, torch.cat([q.detach().reshape(-1) for q in m.parameters()]).cpu()))
+    assert out[0][0] == out[1][0]
+    assert torch.equal(out[0][1], out[1][1])
+
+
 def test_predict_input_buffer_skips_the_staging_copy():
     """predict_step handed its own staging buffer (LSSD3D.predict_input_buffer) returns what it returns for a separate tensor."""
     size, n = (64, 64, 64), 2
