@@ -401,7 +401,9 @@ class LSSD3D(nn.Module):
                       # the four output buffers are views of ONE allocation [labels | prior indices | boxes | scores], so
                       # that a batch's detections leave the workspace with one device copy instead of four
                       out_all=torch.empty(N * top_k * 44, dtype=torch.uint8, device=dev),
-                      oc=torch.zeros(N, dtype=i32, device=dev),
+                      # per-image detection counts + one spare int: predict_step's eval plan keeps its NaN flag there, so that
+                      # counts and flag leave the device with ONE copy
+                      oc=torch.zeros(N + 1, dtype=i32, device=dev),
                       # pinned landing zone of the per-image detection counts (+ one slot for a NaN flag): filled by async
                       # copies, read after ONE stream synchronisation (a blocking 4-byte device-to-host copy costs 50-100 us)
                       host=torch.empty(N + 1, dtype=i32).pin_memory())
@@ -449,9 +451,12 @@ class LSSD3D(nn.Module):
         host = hosts.get(slot)
         if host is None:
             host = hosts[slot] = torch.empty_like(w["host"]).pin_memory()
-        host[:N].copy_(w["oc"], non_blocking=True)
-        if nan_flag is not None:
-            host[N:].copy_(nan_flag, non_blocking=True)
+        if nan_flag is not None and nan_flag.data_ptr() == w["oc"][N:].data_ptr():
+            host.copy_(w["oc"], non_blocking=True)  # counts and the plan's NaN flag (its home is oc[N]) in one copy
+        else:
+            host[:N].copy_(w["oc"][:N], non_blocking=True)
+            if nan_flag is not None:
+                host[N:].copy_(nan_flag, non_blocking=True)
         v = LSSD3D._detect_out_views(w["out_all"].clone(), *w["ol"].shape)  # one copy for all four outputs
         evs = w.setdefault("events", {})
         ev = evs.get(slot)
@@ -578,10 +583,14 @@ class LSSD3D(nn.Module):
         if ent is None:
             buf = torch.empty(x.shape, dtype=torch.float32, device=dev)
             buf.copy_(x, non_blocking=True)
+            # the eval plan's NaN flag moves into the spare int behind the detection counts (one device-to-host copy per pass
+            # instead of two); every launch recorded below takes the flag's address from the plan
+            w = self._detect_workspace(x.size(0), self.priors_cxcycz.size(0), self.n_classes, int(self.top_k), dev)
+            eng.plan_for(buf, False).nan_flag = w["oc"][x.size(0):]
             _lib.start_recording()
             try:
                 locs, scores = eng.forward(buf, training=False, need_grad=False)
-                w = self._detect_workspace(locs.size(0), locs.size(1), scores.size(2), int(self.top_k), dev)
+                assert (locs.size(0), locs.size(1), scores.size(2)) == (x.size(0), self.priors_cxcycz.size(0), self.n_classes)
                 self._detect_launch(locs, scores, w, self.min_score, self.max_overlap, self.top_k)
             finally:
                 prog = _lib.stop_recording()
