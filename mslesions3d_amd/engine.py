@@ -470,6 +470,16 @@ class Engine:
         feats = m.base.features
         specs = self.layer_specs
         ev_pack = None
+        if not training:
+            # eval mode: (scale, shift) of all BatchNorms depend on parameters and running statistics only - one launch.  It
+            # is the FIRST launch of the pass, in front of the prologue's fork: the fork's record then rides on it as a stop
+            # event instead of being a packet of its own at the head of the chain (the heads stream still starts behind
+            # everything the chain held before this pass)
+            every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], 1.0)]
+            for i in range(1, len(specs)):
+                every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], 1.0),
+                          (feats[i].bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], 1.0)]
+            self._finalize_all(pl, every, st, eval_mode=True)
         if self.multi_stream and self.prologue_on_side:
             # the NaN-flag reset and the MFMA-fragment copies of the head weights are needed 200 us into the pass (first head
             # convolution) and at its end (loss / NaN checks): on the heads stream they cost the dependency chain nothing
@@ -504,14 +514,6 @@ class Engine:
             for fn in deferred:
                 fn()
             deferred = []
-
-        if not training:
-            # eval mode: (scale, shift) of all BatchNorms depend on parameters and running statistics only - one launch
-            every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], pl.np_y[0], 1.0)]
-            for i in range(1, len(specs)):
-                every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], pl.np_z[i], 1.0),
-                          (feats[i].bn2, pl.bn_y[i], pl.part_y[i], pl.np_y[i], 1.0)]
-            self._finalize_all(pl, every, st, eval_mode=True)
 
         # stem (features[0] = Conv3d + BN + ReLU)
         D, H, W = pl.in_dims
@@ -747,6 +749,11 @@ class Engine:
         ncls = m.n_classes
         side_prologue = ms and self.prologue_on_side and pl.f32_heads  # as in the fp32 forward: off the dependency chain
         ev_pack = None
+        if not training:  # first launch of the pass, in front of the prologue's fork (see the fp32 pass)
+            every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], 1, 1.0)]
+            for i in range(1, len(specs)):
+                every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], 1, 1.0), (feats[i].bn2, pl.bn_y[i], pl.part_y[i], 1, 1.0)]
+            self._finalize_all(pl, every, st, eval_mode=True)
         if side_prologue:
             if not self.prologue_presynced:
                 self._fork(pl, "fwd_start", st, stH)
@@ -755,11 +762,6 @@ class Engine:
             ev_pack = self._record(pl, "head_pack_done", stH)
         else:
             _lib.call("msl_fill_u32", ptr(pl.nan_flag), 0, 1, st)
-        if not training:
-            every = [(feats[0][1], pl.bn_y[0], pl.part_y[0], 1, 1.0)]
-            for i in range(1, len(specs)):
-                every += [(feats[i].bn1, pl.bn_z[i], pl.part_z[i], 1, 1.0), (feats[i].bn2, pl.bn_y[i], pl.part_y[i], 1, 1.0)]
-            self._finalize_all(pl, every, st, eval_mode=True)
         if pl.f32_heads and not side_prologue:  # MFMA-fragment copies of the head weights (forward and, in training, bwd-data)
             self._pack_head_weights(pl, st)
         part = (lambda t: ptr(t)) if training else (lambda t: None)
